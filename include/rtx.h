@@ -1,0 +1,193 @@
+/*
+ * rtx.h -- C ABI of the MI355X (gfx950) render hot path for sky-5462/RayTracer.
+ *
+ * The reference has no plugin or FFI seam of its own: its only public method is
+ * RayTracer::parseConfigFile (include/RayTracer/RayTracer.h:14) and the hot path is the body
+ * of the frame loop in RayTracer::render (src/RayTracer.cpp:237-260).  This header is the seam
+ * a maintainer would bind at that loop: the inputs are exactly the reference's private
+ * members (RayTracer.h:17-31) in their in-memory layouts, the output is accumulateImg
+ * (RayTracer.h:20).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Two libraries implement it:
+ *   librtx_hip.so   rtx_*   device side (HIP kernels, gfx950)            raytracer_amd/csrc/rtx_hip.hip
+ *   librtx_host.so  rtxh_*  host-side scene preparation (no GPU needed)  raytracer_amd/csrc/rtx_host.cpp
+ *
+ * Conventions: every function returns 0 on success or a negative rtx_status; the message
+ * of the last failure on the calling thread is rtx_last_error()/rtxh_last_error().  No
+ * exception crosses the boundary.  The caller owns every host buffer it passes; set_* calls
+ * copy synchronously.  One host thread drives a scene at a time.
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rtx_status {
+	RTX_OK = 0,
+	RTX_ERR_ARG = -1,      /* bad argument, inconsistent scene, size beyond a documented limit */
+	RTX_ERR_STATE = -2,    /* call order: e.g. render before the scene is complete */
+	RTX_ERR_DEVICE = -3,   /* a HIP call failed; rtx_last_error() holds hipGetErrorString */
+	RTX_ERR_MEMORY = -4    /* device or host allocation failed */
+} rtx_status;
+
+/* Byte sizes of the reference's records as this ABI expects them. */
+#define RTX_TRIANGLE_BYTES 176 /* class Triangle,    include/RayTracer/Triangle.h:6-34  */
+#define RTX_NODE_BYTES 48      /* struct LinearNode, include/RayTracer/BVH.h:35-43      */
+
+typedef struct rtx_scene rtx_scene; /* opaque; owns all device memory of one scene on one GPU */
+
+/* Counters of the most recent rtx_render_frames / rtx_primary_hits call. */
+typedef struct rtx_stats {
+	uint64_t rays;            /* color()-equivalent queries traced (primary + secondary + last-depth occlusion) */
+	uint64_t rays_per_level[16];
+	uint64_t node_tests;      /* AABB::hit-equivalent box tests (only filled by instrumented runs) */
+	uint64_t tri_tests;       /* Triangle::hit-equivalent tests   (only filled by instrumented runs) */
+	uint64_t shaded_hits;     /* hits that reached the material branch */
+	uint64_t texture_fetches; /* texture + skybox texel fetches */
+	double trace_ms;          /* sum of HIP-event durations of the traversal kernels */
+	double shade_ms;          /* ... of the shade / gather / accumulate kernels */
+	double total_ms;          /* HIP-event time of the whole call on the scene's stream */
+	uint32_t trace_launches;
+	uint32_t chunks;          /* number of pixel batches the frame(s) were split into */
+} rtx_stats;
+
+/* ------------------------------------------------------------------ device side (librtx_hip.so) */
+
+const char* rtx_last_error(void);
+
+/* Number of visible HIP devices, or a negative rtx_status. */
+int rtx_device_count(void);
+
+/* Creates an empty scene bound to HIP device `device`.  Replaces: construction of the
+ * RayTracer object (src/main.cpp:9). */
+int rtx_scene_create(rtx_scene** out, int device);
+int rtx_scene_destroy(rtx_scene* s);
+
+/* Work is enqueued on `hip_stream` (a hipStream_t; NULL selects a stream the scene owns).
+ * Calls still block until their work has finished unless stated otherwise. */
+int rtx_scene_set_stream(rtx_scene* s, void* hip_stream);
+
+/* Image size and the scalar members diffuseRayNum, specualrRayNum, maxRecursionDepth,
+ * backgroundColor (RayTracer.h:17-18,28-31; parsed at src/RayTracer.cpp:287-332).
+ * `seed` keys the counter-based RNG that replaces the reference's thread_local
+ * std::mt19937 pair (src/Triangle.cpp:96,122).  Limits: 1 <= max_depth <= 15,
+ * 1 <= n_diffuse, n_specular <= 64. */
+int rtx_scene_set_params(rtx_scene* s, int width, int height, int max_depth, int n_diffuse, int n_specular,
+						 const float background_rgb[3], uint64_t seed);
+
+/* The four Camera members after Camera::setCamera (include/RayTracer/Camera.h:15-18,
+ * src/Camera.cpp:4-32), four floats each. */
+int rtx_scene_set_camera(rtx_scene* s, const float origin[4], const float left_up_corner[4],
+						 const float right_step[4], const float down_step[4]);
+
+/* trianglesArray (RayTracer.h:22): n records of RTX_TRIANGLE_BYTES in the reference's layout. */
+int rtx_scene_set_triangles(rtx_scene* s, const void* triangles, uint32_t n);
+
+/* BVH::linearTree (include/RayTracer/BVH.h:53) as produced by BVH::buildTree
+ * (src/BVH.cpp:51-160): n records of RTX_NODE_BYTES, root at index 0.  Must be called after
+ * rtx_scene_set_triangles; the tree is validated (child indices, one leaf per triangle,
+ * depth <= 32) and re-flattened into the device layout. */
+int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n);
+
+/* One entry of texturesArray (RayTracer.h:23): `rgb` is Texture::data as the reference
+ * holds it after its vertically flipped 3-channel load (src/Texture.cpp:6-7), w*h*3 bytes.
+ * Returns the texture id (>= 0) that Triangle::textureIndex refers to. */
+int rtx_scene_add_texture(rtx_scene* s, const uint8_t* rgb, int width, int height);
+
+/* Skybox::brightness and the six Skybox::backgroundImg faces (include/RayTracer/Skybox.h:23-24)
+ * in the order front, back, left, right, top, bottom (src/Skybox.cpp:13-15), given as
+ * texture ids from rtx_scene_add_texture.  Without this call misses return the background
+ * colour (src/RayTracer.cpp:154-159). */
+int rtx_scene_set_skybox(rtx_scene* s, float brightness, const int texture_ids[6]);
+
+/* Host-computed lookup tables so that no device libm result enters the image:
+ * cosTable/sinTable (src/Triangle.cpp:8-21) and powf(c/255.0f, 2.2f) for c = 0..255
+ * (src/Texture.cpp:49-51). */
+int rtx_scene_set_tables(rtx_scene* s, const float cos512[512], const float sin512[512], const float gamma256[256]);
+
+/* Restricts rendering to the image tiles (64x64 pixels, row-major tile index) first,
+ * first+stride, ... (count of them; count < 0 = all that exist).  This is how one GPU of
+ * several takes its share of the row loop (src/RayTracer.cpp:237).  Default: all tiles. */
+int rtx_scene_set_tiles(rtx_scene* s, int first, int stride, int count);
+
+/* Upper bound in bytes for the per-frame work arena (ray, hit and path-node queues).
+ * 0 selects the default (a fraction of free device memory). */
+int rtx_scene_set_arena_bytes(rtx_scene* s, uint64_t bytes);
+
+/* Uses caller-owned device memory (height*width*4 floats, row-major, the layout of
+ * accumulateImg, RayTracer.h:20) as the accumulator instead of the scene's own buffer;
+ * NULL switches back. */
+int rtx_scene_set_accum_device(rtx_scene* s, void* device_rgba);
+
+/* accumulateImg.fill(Zero) (src/RayTracer.cpp:230). */
+int rtx_accum_reset(rtx_scene* s);
+
+/* The loop body of RayTracer::render for frames i = first_frame .. first_frame+n_frames-1
+ * (1-based like `i` at src/RayTracer.cpp:234): camera rays, traversal, intersection, bounce
+ * loop, accumulateImg(row,col) += sum*0.25f (src/RayTracer.cpp:237-246).  The tone map and PNG
+ * write stay with the caller. */
+int rtx_render_frames(rtx_scene* s, uint32_t first_frame, uint32_t n_frames);
+
+/* Copies the accumulator to host memory: height*width*4 floats. */
+int rtx_accum_read(rtx_scene* s, float* host_rgba);
+/* Uploads an accumulator (resuming from a saved image). */
+int rtx_accum_write(rtx_scene* s, const float* host_rgba);
+
+/* Closest hit of every primary ray (the head of RayTracer::color, src/RayTracer.cpp:137-151,
+ * applied to Camera::getRay, src/Camera.cpp:40-49): tri_ids[height*width*4] (reference triangle
+ * index or -1), t_alpha_beta[height*width*4*3] (may be NULL).  Sample order: (row*width+col)*4+k.
+ * mode 0 = production traversal (ordered, culled); 1 = exhaustive traversal that visits exactly
+ * the nodes BVH::hit visits (src/BVH.cpp:162-192), for cross-checking. */
+int rtx_primary_hits(rtx_scene* s, int mode, int32_t* tri_ids, float* t_alpha_beta);
+
+/* Closest hit of n arbitrary rays (origins/directions as xyz triples), same modes. */
+int rtx_trace_rays(rtx_scene* s, int mode, uint32_t n, const float* origins, const float* directions,
+				   int32_t* tri_ids, float* t_alpha_beta);
+
+/* Per-sample radiance of one frame before accumulation, i.e. color(0, ray) for every
+ * primary ray: out[height*width*4][4].  Tiles outside the scene's tile set are left untouched. */
+int rtx_sample_radiance(rtx_scene* s, uint32_t frame, float* host_out);
+
+/* When enabled, traversal kernels count box and triangle tests (slower). */
+int rtx_scene_set_instrumented(rtx_scene* s, int enabled);
+int rtx_get_stats(rtx_scene* s, rtx_stats* out);
+
+/* ------------------------------------------------------------------ host side (librtx_host.so) */
+
+const char* rtxh_last_error(void);
+
+/* Camera::setCamera (src/Camera.cpp:4-32).  out16 = origin, leftUpCorner, rightStep, downStep. */
+int rtxh_camera(const float eye[3], const float view_point[3], float focal, float rotate_deg, int width, int height,
+				float out16[16]);
+
+/* BVH::buildTree (src/BVH.cpp:51-160): writes the node records (capacity in records;
+ * 3n+1 always suffices: n leaves plus at most 2n-1 interior nodes) and returns the node count, or a
+ * negative rtx_status. */
+int rtxh_build_bvh(const void* triangles, uint32_t n, void* nodes_out, uint32_t capacity);
+
+/* RayTracer::addTriangle (src/RayTracer.cpp:108-134): fills one RTX_TRIANGLE_BYTES record. */
+int rtxh_make_triangle(const float v0[3], const float v1[3], const float v2[3], const float normal_side[3],
+					   const float color[3], int is_metal, int is_light_emitting, int is_transparent,
+					   float specular_roughness, float refractive_index, void* triangle_out);
+
+/* The static tables of src/Triangle.cpp:8-21 and the texel decode of src/Texture.cpp:49-51. */
+int rtxh_tables(float cos512[512], float sin512[512], float gamma256[256]);
+
+/* Tone map of src/RayTracer.cpp:248-257: rgb8[npix*3] from accum[npix*4] after `frame` frames. */
+int rtxh_tonemap(const float* accum_rgba, int frame, size_t npix, uint8_t* rgb8);
+
+/* Whole drop-in: parse `config_path` with the grammar of RayTracer::parseConfigFile
+ * (src/RayTracer.cpp:284-518), render on `n_devices` GPUs (device ids 0..n-1) and write
+ * out_%03d.png into `out_dir` after every frame like src/RayTracer.cpp:263-271.
+ * Implemented in librtx_host.so on top of librtx_hip.so, which it loads at run time. */
+int rtxh_run_config(const char* config_path, const char* out_dir, int n_devices);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */

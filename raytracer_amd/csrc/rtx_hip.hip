@@ -1,0 +1,1695 @@
+// MI355X (gfx950, wave64) implementation of the render hot path of sky-5462/RayTracer
+// behind the C ABI of include/rtx.h.
+//
+// What the reference does per pixel on the CPU (src/RayTracer.cpp:237-246: four camera rays,
+// a branching recursive color(), accumulate) is done here as a wavefront pipeline:
+//
+//   raygen            Camera::getRay (src/Camera.cpp:40-49) for a batch of pixel blocks
+//   per path level d: trace   BVH::hit + Triangle::hit + closest-hit select
+//                             (src/BVH.cpp:162-192, src/Triangle.cpp:23-93, src/RayTracer.cpp:139-151)
+//                     shade   miss/sky, normal, termination, emission, child-ray generation
+//                             (src/RayTracer.cpp:154-214, src/Triangle.cpp:95-179), children appended
+//                             to the next level's queue with wave64 ballot/popcount prefix sums
+//   per level, deepest first: gather  the reference's own combine formulas
+//                             (src/RayTracer.cpp:184,193-197,205-222) over each node's children
+//   accumulate        accumulateImg(row,col) += (sum of 4 samples) * 0.25f (src/RayTracer.cpp:242-246)
+//
+// Because every node's children occupy consecutive queue slots, the gather pass adds them in
+// the reference's order and applies the reference's scale factors afterwards (sum, then
+// scale), so the accumulator is bit-identical to the recursive evaluation, not merely close.
+//
+// Arithmetic discipline (compile with -ffp-contract=off, IEEE divide/sqrt, no fast-math):
+// every expression below is written in the evaluation order Eigen gives the reference
+// (4-float dot = (x+z)+(y+w), w lanes are zero), fused multiply-adds appear only where the
+// reference has explicit FMA intrinsics (src/Triangle.cpp:66,79), and transcendental values
+// come from host-computed tables.
+//
+// Traversal visits exactly the candidates the reference visits (same slab predicate per
+// node, src/BVH.cpp:14-41) minus nodes that provably cannot hold the winner: boxes wholly
+// behind t = 0.001 or wholly beyond the best hit so far, judged on boxes inflated by a
+// position-space safety margin.  Equal-t ties are resolved by the reference's depth-first
+// (right child first) candidate order, which is precomputed per triangle.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtx.h"
+
+#define RTX_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+	g_err = msg;
+	return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+	do {                                                                                               \
+		hipError_t e_ = (expr);                                                                        \
+		if (e_ != hipSuccess)                                                                          \
+			return fail(RTX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+	} while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Device-side scene description, passed to kernels by value.
+
+constexpr int TILE = 64;            // image tile edge in pixels (sharding granule)
+constexpr int BLK = 4;              // a wave covers a BLK x BLK pixel block x 4 sub-samples
+constexpr int BLOCKS_PER_TILE = (TILE / BLK) * (TILE / BLK);
+constexpr int SAMPLES_PER_BLOCK = BLK * BLK * 4;  // 64 = one wave
+constexpr int TRACE_THREADS = 256;
+
+enum NodeKind : int { KIND_LEAF = 0, KIND_METAL = 1, KIND_TRANSP = 2, KIND_DIEL = 3 };
+constexpr int FLAG_TEX = 0x100;
+constexpr int FLAG_TIR = 0x200;
+
+constexpr int TRI_EMIT = 1, TRI_METAL = 2, TRI_TRANSP = 4;
+
+struct DevScene {
+	const float4* pairs;     // 4 x float4 per child pair: Lmin|codeL, Lmax|-, Rmin|codeR, Rmax|-
+	const float4* triHit;    // 4 x float4 per triangle in candidate-rank order
+	const float4* triShade;  // 6 x float4 per triangle in candidate-rank order
+	const uint8_t* texels;
+	const int4* texDesc;     // byte offset, width, height
+	const float* cosT;
+	const float* sinT;
+	const float* gammaT;
+	float4 camO, camLUC, camRS, camDS;
+	float4 bg;
+	int width, height, maxDepth, nDiff, nSpec;
+	int hasSky;
+	float skyBrightness;
+	int skyTex[6];
+	uint32_t seedKey;
+	float sceneAbsMax;
+	int tilesX;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Small device helpers.  dot4 is Eigen's reduction order with the (zero) w lane kept as "+ 0.0f".
+
+__device__ __forceinline__ float dot3w(float ax, float ay, float az, float bx, float by, float bz) {
+	return (ax * bx + az * bz) + (ay * by + 0.0f);
+}
+
+__device__ __forceinline__ uint32_t rt_mix(uint32_t h, uint32_t v) {
+	h = (h + 0x7F4A7C15u) ^ (v * 0x9E3779B1u);
+	h ^= h >> 16;
+	h *= 0x85EBCA6Bu;
+	h ^= h >> 13;
+	h *= 0xC2B2AE35u;
+	h ^= h >> 16;
+	return h;
+}
+__device__ __forceinline__ uint32_t rt_child_key(uint32_t key, uint32_t ordinal) { return rt_mix(key, 1u + ordinal); }
+__device__ __forceinline__ uint32_t rt_draw(uint32_t key, uint32_t lobe, uint32_t k, uint32_t dim) {
+	return rt_mix(key, 0x80000000u | (lobe << 20) | (k << 1) | dim);
+}
+
+__device__ __forceinline__ float clamp01(float u) {
+	u = (u >= 0.0f) ? u : 0.0f;
+	u = (u <= 1.0f) ? u : 1.0f;
+	return u;
+}
+
+// Texture::sampleTexture (src/Texture.cpp:41-53) with clamped coordinates and the
+// powf(c/255, 2.2) decode taken from the host-computed table.
+__device__ __forceinline__ float3 tex_fetch(const DevScene& sc, int id, float u, float v) {
+	int4 d = sc.texDesc[id];
+	u = clamp01(u);
+	v = clamp01(v);
+	float uMax = (float)(d.y - 1);
+	float vMax = (float)(d.z - 1);
+	int sx = (int)roundf(u * uMax);
+	int sy = (int)roundf(v * vMax);
+	const uint8_t* c = sc.texels + (size_t)(uint32_t)d.x + ((size_t)sy * (size_t)d.y + (size_t)sx) * 3;
+	return make_float3(sc.gammaT[c[0]], sc.gammaT[c[1]], sc.gammaT[c[2]]);
+}
+
+// Skybox::sampleBackground (src/Skybox.cpp:32-84).
+__device__ float3 sky_fetch(const DevScene& sc, float dx, float dy, float dz) {
+	for (int i = 0; i < 6; ++i) {
+		float divisor, u, v;
+		float px, py, pz;
+		switch (i) {
+		case 0:
+			divisor = dz;
+			px = dx / divisor; py = dy / divisor;
+			u = (1.0f - px) * 0.5f;
+			v = (1.0f + py) * 0.5f;
+			break;
+		case 1:
+			divisor = -dz;
+			px = dx / divisor; py = dy / divisor;
+			u = (1.0f + px) * 0.5f;
+			v = (1.0f + py) * 0.5f;
+			break;
+		case 2:
+			divisor = -dx;
+			pz = dz / divisor; py = dy / divisor;
+			u = (1.0f - pz) * 0.5f;
+			v = (1.0f + py) * 0.5f;
+			break;
+		case 3:
+			divisor = dx;
+			pz = dz / divisor; py = dy / divisor;
+			u = (pz + 1.0f) * 0.5f;
+			v = (py + 1.0f) * 0.5f;
+			break;
+		case 4:
+			divisor = dy;
+			px = dx / divisor; pz = dz / divisor;
+			u = (px + 1.0f) * 0.5f;
+			v = (pz + 1.0f) * 0.5f;
+			break;
+		default:
+			divisor = -dy;
+			px = dx / divisor; pz = dz / divisor;
+			u = (px + 1.0f) * 0.5f;
+			v = (pz - 1.0f) * 0.5f;
+			break;
+		}
+		if (divisor < 0.0f || u < 0.0f || v < 0.0f || u > 1.0f || v > 1.0f) continue;
+		float3 c = tex_fetch(sc, sc.skyTex[i], u, v);
+		return make_float3(c.x * sc.skyBrightness, c.y * sc.skyBrightness, c.z * sc.skyBrightness);
+	}
+	return make_float3(0.0f, 0.0f, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Level-0 sample order.  Sample j of a batch that starts at pixel block g0:
+//   block g = g0 + j/64 -> (tile slot, block in tile); lane = j%64 -> (pixel in block, sub-sample).
+// A wave therefore holds the 4 sub-samples of a 4x4 pixel block, which keeps primary rays of
+// one wave spatially adjacent.  Tiles are taken from the arithmetic list first + k*stride.
+
+struct Batch {
+	int g0;          // first pixel block (global over the scene's tile list)
+	int nSamples;    // (number of blocks) * 64
+	int tileFirst, tileStride;
+};
+
+__device__ __forceinline__ bool sample_to_pixel(const DevScene& sc, const Batch& b, int j, int& x, int& y, int& sub) {
+	int g = b.g0 + (j >> 6);
+	int lane = j & 63;
+	int slot = g / BLOCKS_PER_TILE;
+	int blk = g - slot * BLOCKS_PER_TILE;
+	int tile = b.tileFirst + slot * b.tileStride;
+	int ty = tile / sc.tilesX;
+	int tx = tile - ty * sc.tilesX;
+	int by = blk / (TILE / BLK);
+	int bx = blk - by * (TILE / BLK);
+	int pix = lane >> 2;
+	sub = lane & 3;
+	x = tx * TILE + bx * BLK + (pix & 3);
+	y = ty * TILE + by * BLK + (pix >> 2);
+	return x < sc.width && y < sc.height;
+}
+
+// Camera::getRay (src/Camera.cpp:37-49) plus the per-sample RNG key.
+__global__ __launch_bounds__(256) void k_raygen(DevScene sc, Batch b, uint32_t frame, float4* __restrict__ rayO,
+												float4* __restrict__ rayD) {
+	int j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= b.nSamples) return;
+	int x, y, sub;
+	bool valid = sample_to_pixel(sc, b, j, x, y, sub);
+	if (!valid) {
+		rayO[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		rayD[j] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);  // w = 1 marks a dead slot
+		return;
+	}
+	const float xo = (sub & 1) ? 0.25f : -0.25f;
+	const float yo = (sub & 2) ? 0.25f : -0.25f;
+	float xTemp = (float)x + xo;
+	float yTemp = (float)y + yo;
+	float dx = (sc.camLUC.x + xTemp * sc.camRS.x) + yTemp * sc.camDS.x;
+	float dy = (sc.camLUC.y + xTemp * sc.camRS.y) + yTemp * sc.camDS.y;
+	float dz = (sc.camLUC.z + xTemp * sc.camRS.z) + yTemp * sc.camDS.z;
+	uint32_t sample = ((uint32_t)y * (uint32_t)sc.width + (uint32_t)x) * 4u + (uint32_t)sub;
+	uint32_t key = rt_mix(rt_mix(sc.seedKey, frame), sample);
+	rayO[j] = make_float4(sc.camO.x, sc.camO.y, sc.camO.z, __uint_as_float(key));
+	rayD[j] = make_float4(dx, dy, dz, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Traversal.
+
+struct HitState {
+	float t, alpha, beta;
+	int rank;
+};
+
+// Triangle::hit (src/Triangle.cpp:23-93) against the triangle stored at `rank`, folded with
+// the closest-hit rule of src/RayTracer.cpp:145 extended by the candidate-order tie break.
+// Returns true when the triangle was accepted (any-hit callers stop there).
+__device__ __forceinline__ bool tri_test(const float4* __restrict__ triHit, int rank, float ox, float oy, float oz,
+										 float dx, float dy, float dz, HitState& best) {
+	const float4* T = triHit + (size_t)rank * 4;
+	float4 q0 = T[0], q1 = T[1], q2 = T[2], q3 = T[3];
+	// q0 = n.xyz v0.x | q1 = v0.yz v2.xy | q2 = v2.z a1.xyz | q3 = a2.xyz id
+	float temp = dot3w(q0.x, q0.y, q0.z, q0.w - ox, q1.x - oy, q1.y - oz);
+	float t = temp / dot3w(q0.x, q0.y, q0.z, dx, dy, dz);
+	if (!(t > 0.001f)) return false;
+	if (t > best.t || (t == best.t && rank > best.rank)) return false;
+	float bx = (ox + t * dx) - q1.z;
+	float by = (oy + t * dy) - q1.w;
+	float bz = (oz + t * dz) - q2.x;
+	// rows (a1_i, a2_i, b_i), i = x,y,z
+	float r00 = q2.y, r01 = q3.x, r02 = bx;
+	float r10 = q2.z, r11 = q3.y, r12 = by;
+	float r20 = q2.w, r21 = q3.z, r22 = bz;
+	// first pivot: largest |column 0|, strict >, rows tried in order 0,1,2
+	bool s1 = fabsf(r10) > fabsf(r00);
+	float mx = s1 ? fabsf(r10) : fabsf(r00);
+	bool s2 = fabsf(r20) > mx;
+	float p0 = s2 ? r20 : (s1 ? r10 : r00);
+	float p1 = s2 ? r21 : (s1 ? r11 : r01);
+	float p2 = s2 ? r22 : (s1 ? r12 : r02);
+	bool m1 = s1 && !s2;
+	float a0 = m1 ? r00 : r10, a1 = m1 ? r01 : r11, a2 = m1 ? r02 : r12;  // new row 1
+	float c0 = s2 ? r00 : r20, c1 = s2 ? r01 : r21, c2 = s2 ? r02 : r22;  // new row 2
+	p1 = p1 / p0;
+	p2 = p2 / p0;
+	a1 = __fmaf_rn(-p1, a0, a1);
+	a2 = __fmaf_rn(-p2, a0, a2);
+	c1 = __fmaf_rn(-p1, c0, c1);
+	c2 = __fmaf_rn(-p2, c0, c2);
+	// second pivot
+	bool s3 = fabsf(c1) > fabsf(a1);
+	float e1 = s3 ? c1 : a1;
+	float e2 = s3 ? c2 : a2;
+	e2 = e2 / e1;
+	float alpha = __fmaf_rn(-e2, p1, p2);
+	float beta = e2;
+	bool accept = (0.0f <= alpha) & (alpha <= 1.0f) & (0.0f <= beta) & (beta <= 1.0f) & (alpha + beta <= 1.0f);
+	if (!accept) return false;
+	best.t = t;
+	best.alpha = alpha;
+	best.beta = beta;
+	best.rank = rank;
+	return true;
+}
+
+// Per-ray constants of the slab test.
+struct RaySlab {
+	float ox, oy, oz, ix, iy, iz, mx, my, mz;
+	bool nx, ny, nz;
+};
+
+// AABB::hit (src/BVH.cpp:14-41) for one box, plus the conservative entry/exit bounds used
+// for culling.  The folds over lanes 1 and 2 ignore NaN exactly like the reference's
+// "t0 > tmin ? t0 : tmin"; a NaN in lane 0 makes the reference's final comparison false,
+// i.e. a hit, which the unordered test reproduces.
+__device__ __forceinline__ bool box_test(const RaySlab& r, float4 bmin, float4 bmax, float& te, float& tx) {
+	float t0x = (bmin.x - r.ox) * r.ix, t1x = (bmax.x - r.ox) * r.ix;
+	float t0y = (bmin.y - r.oy) * r.iy, t1y = (bmax.y - r.oy) * r.iy;
+	float t0z = (bmin.z - r.oz) * r.iz, t1z = (bmax.z - r.oz) * r.iz;
+	float nX = r.nx ? t1x : t0x, fX = r.nx ? t0x : t1x;
+	float nY = r.ny ? t1y : t0y, fY = r.ny ? t0y : t1y;
+	float nZ = r.nz ? t1z : t0z, fZ = r.nz ? t0z : t1z;
+	float tmin = fmaxf(fmaxf(nX, nY), nZ);
+	float tmax = fminf(fminf(fX, fY), fZ);
+	bool hit = !(tmax < tmin) || (nX != nX) || (fX != fX);
+	te = fmaxf(fmaxf(nX - r.mx, nY - r.my), nZ - r.mz);
+	tx = fminf(fminf(fX + r.mx, fY + r.my), fZ + r.mz);
+	return hit;
+}
+
+// hits[j] = (rank or -1 / -2 for a dead slot, t, alpha, beta), all as raw bits of a float4.
+// ANYHIT: only "some candidate is accepted" is needed (rays at the last recursion depth,
+// src/RayTracer.cpp:154-171); x = 0 then stands for "hit".
+// EXHAUSTIVE: no culling, i.e. the candidate set of BVH::hit itself.
+template <int STACK, bool ANYHIT, bool EXHAUSTIVE, bool STATS>
+__global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const float4* __restrict__ rayO,
+														  const float4* __restrict__ rayD, float4* __restrict__ hits,
+														  int n, unsigned long long* __restrict__ stats) {
+	__shared__ int stk[STACK][TRACE_THREADS];
+	const int tid = threadIdx.x;
+	const int j = blockIdx.x * TRACE_THREADS + tid;
+	unsigned nodeTests = 0, triTests = 0;
+	if (j < n) {
+		float4 O = rayO[j];
+		float4 D = rayD[j];
+		if (D.w != 0.0f) {
+			hits[j] = make_float4(__int_as_float(-2), FLT_MAX, 0.0f, 0.0f);
+		}
+		else {
+			RaySlab r;
+			r.ox = O.x; r.oy = O.y; r.oz = O.z;
+			const float dx = D.x, dy = D.y, dz = D.z;
+			r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
+			r.nx = (__float_as_uint(r.ix) >> 31) != 0;
+			r.ny = (__float_as_uint(r.iy) >> 31) != 0;
+			r.nz = (__float_as_uint(r.iz) >> 31) != 0;
+			// Position-space slack for culling: 2^-14 of the largest coordinate magnitude in play.
+			float scale = fmaxf(fmaxf(sc.sceneAbsMax, fabsf(r.ox)), fmaxf(fabsf(r.oy), fabsf(r.oz)));
+			float eps = scale * 6.103515625e-05f;
+			r.mx = eps * fabsf(r.ix); r.my = eps * fabsf(r.iy); r.mz = eps * fabsf(r.iz);
+			HitState best;
+			best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
+			bool found = false;
+			int sp = 0;
+			int cur = 0;
+			while (cur >= 0) {
+				const float4* P = sc.pairs + (size_t)cur * 4;
+				float4 lmin = P[0], lmax = P[1], rmin = P[2], rmax = P[3];
+				int codeL = __float_as_int(lmin.w);
+				int codeR = __float_as_int(rmin.w);
+				float teL, txL, teR, txR;
+				bool hitL = box_test(r, lmin, lmax, teL, txL) && codeL != 0;
+				bool hitR = box_test(r, rmin, rmax, teR, txR) && codeR != 0;
+				if (STATS) nodeTests += (codeL != 0) + (codeR != 0);
+				if (!EXHAUSTIVE) {
+					hitL = hitL && !(txL < 0.001f) && !(teL > best.t);
+					hitR = hitR && !(txR < 0.001f) && !(teR > best.t);
+				}
+				if (hitL && codeL < 0) {
+					if (STATS) triTests++;
+					found |= tri_test(sc.triHit, ~codeL, r.ox, r.oy, r.oz, dx, dy, dz, best);
+				}
+				if (hitR && codeR < 0 && !(ANYHIT && found)) {
+					if (STATS) triTests++;
+					found |= tri_test(sc.triHit, ~codeR, r.ox, r.oy, r.oz, dx, dy, dz, best);
+				}
+				if (ANYHIT && found) break;
+				bool intL = hitL && codeL > 0;
+				bool intR = hitR && codeR > 0;
+				if (!EXHAUSTIVE) {
+					intL = intL && !(teL > best.t);
+					intR = intR && !(teR > best.t);
+				}
+				int next = -1;
+				if (intL && intR) {
+					bool lfirst = teL <= teR;
+					next = lfirst ? codeL : codeR;
+					if (sp < STACK) {  // the host rejects trees deeper than the stack
+						stk[sp][tid] = lfirst ? codeR : codeL;
+						sp++;
+					}
+				}
+				else if (intL) next = codeL;
+				else if (intR) next = codeR;
+				else if (sp > 0) {
+					sp--;
+					next = stk[sp][tid];
+				}
+				cur = next;
+			}
+			int id = found ? (ANYHIT ? 0 : best.rank) : -1;
+			hits[j] = make_float4(__int_as_float(id), best.t, best.alpha, best.beta);
+		}
+	}
+	if (STATS) {
+		// wave-level reduction, then one atomic per wave
+		for (int off = 32; off > 0; off >>= 1) {
+			nodeTests += __shfl_down(nodeTests, off, 64);
+			triTests += __shfl_down(triTests, off, 64);
+		}
+		if ((tid & 63) == 0) {
+			atomicAdd(&stats[0], (unsigned long long)nodeTests);
+			atomicAdd(&stats[1], (unsigned long long)triTests);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shade.  One thread per ray of level `level`.  Writes the path-node record of this ray:
+//   A[j]  leaf: its radiance.   interior: triangle colour (replaced by the node's radiance in k_gather)
+//   B[j]  (first child slot, kind | flags, scalar as float bits, -)   scalar = |n.d| (dielectric) or
+//         the refracted proportion (transparent)
+//   C[j]  texel of a textured dielectric
+// and appends the node's child rays to the next level's queue.  cnt[0] receives the queue
+// length, cnt[1] dead slots (refraction under total internal reflection), cnt[2] shaded hits,
+// cnt[3] texel fetches.
+
+__device__ __forceinline__ void scatter_offset(const DevScene& sc, uint32_t key, uint32_t lobe, uint32_t k, float& ox,
+											   float& oy, float& oz) {
+	uint32_t phi = rt_draw(key, lobe, k, 0) & 0x1FFu;
+	uint32_t theta = (rt_draw(key, lobe, k, 1) & 0x1FFu) >> 1;
+	float cp = sc.cosT[phi], sp = sc.sinT[phi], ct = sc.cosT[theta], st = sc.sinT[theta];
+	// horizontal * sin(theta) + cos(theta) * UnitZ, lane by lane (src/Triangle.cpp:107-113)
+	ox = cp * st + ct * 0.0f;
+	oy = sp * st + ct * 0.0f;
+	oz = 0.0f * st + ct * 1.0f;
+}
+
+__global__ __launch_bounds__(256) void k_shade(DevScene sc, int level, const float4* __restrict__ rayO,
+											   const float4* __restrict__ rayD, const float4* __restrict__ hits, int n,
+											   float4* __restrict__ A, int4* __restrict__ B, float4* __restrict__ C,
+											   float4* __restrict__ nRayO, float4* __restrict__ nRayD,
+											   unsigned* __restrict__ cnt, unsigned nextCap) {
+	const int j = blockIdx.x * 256 + threadIdx.x;
+	const int S = sc.nSpec, Dn = sc.nDiff;
+	int kind = KIND_LEAF;
+	int flags = 0;
+	int nchild = 0;
+	float3 val = make_float3(0.0f, 0.0f, 0.0f);
+	float scalar = 0.0f;
+	float3 texel = make_float3(0.0f, 0.0f, 0.0f);
+	// state needed after the allocation
+	float hx = 0, hy = 0, hz = 0, nx = 0, ny = 0, nz = 0, dx = 0, dy = 0, dz = 0, rough = 0, ior = 1;
+	uint32_t key = 0;
+	unsigned dead = 0, shaded = 0, fetches = 0;
+	const bool active = j < n;
+	if (active) {
+		float4 O = rayO[j];
+		float4 D = rayD[j];
+		float4 H = hits[j];
+		int rank = __float_as_int(H.x);
+		key = __float_as_uint(O.w);
+		dx = D.x; dy = D.y; dz = D.z;
+		if (rank == -2) {
+			dead = 1;
+		}
+		else if (rank == -1) {
+			if (sc.hasSky) {
+				val = sky_fetch(sc, dx, dy, dz);
+				fetches = 1;
+			}
+			else
+				val = make_float3(sc.bg.x, sc.bg.y, sc.bg.z);
+		}
+		else if (level < sc.maxDepth) {
+			// (at level == maxDepth every hit returns zero, src/RayTracer.cpp:170; the any-hit
+			//  traversal reports such hits with rank 0, which is never dereferenced)
+			const float4* T = sc.triShade + (size_t)rank * 6;
+			float4 s0 = T[0], s1 = T[1], s2 = T[2], s3 = T[3], s4 = T[4], s5 = T[5];
+			const float t = H.y, alpha = H.z, beta = H.w;
+			const int triFlags = __float_as_int(s5.y);
+			const int texId = __float_as_int(s5.x);
+			hx = O.x + t * dx;
+			hy = O.y + t * dy;
+			hz = O.z + t * dz;
+			float g = 1.0f - (alpha + beta);
+			nx = (alpha * s0.x + beta * s1.x) + g * s2.x;
+			ny = (alpha * s0.y + beta * s1.y) + g * s2.y;
+			nz = (alpha * s0.z + beta * s1.z) + g * s2.z;
+			float z = dot3w(nx, ny, nz, nx, ny, nz);
+			if (z > 0.0f) {
+				float len = sqrtf(z);
+				nx = nx / len;
+				ny = ny / len;
+				nz = nz / len;
+			}
+			float cosine = dot3w(nx, ny, nz, dx, dy, dz);
+			const bool transp = (triFlags & TRI_TRANSP) != 0;
+			if (!transp && cosine >= 0.0f) {
+				// back side: zero
+			}
+			else if (triFlags & TRI_EMIT) {
+				val = make_float3(s0.w, s1.w, s2.w);
+			}
+			else {
+				shaded = 1;
+				val = make_float3(s0.w, s1.w, s2.w);  // colour, consumed by k_gather
+				rough = s4.z;
+				ior = s4.w;
+				if (triFlags & TRI_METAL) {
+					kind = KIND_METAL;
+					nchild = S;
+				}
+				else if (transp) {
+					kind = KIND_TRANSP;
+					nchild = S + 1;
+				}
+				else {
+					kind = KIND_DIEL;
+					nchild = S + Dn;
+					scalar = fabsf(cosine);
+					if (texId >= 0) {
+						flags |= FLAG_TEX;
+						float u = (alpha * s3.x + beta * s3.z) + g * s4.x;
+						float v = (alpha * s3.y + beta * s3.w) + g * s4.y;
+						texel = tex_fetch(sc, texId, u, v);
+						fetches = 1;
+					}
+				}
+			}
+		}
+	}
+
+	// ---- queue slots for the children: per-kind ballots + popcounts give each lane its offset
+	const unsigned lane = threadIdx.x & 63;
+	const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+	unsigned long long bm = __ballot(kind == KIND_METAL);
+	unsigned long long bt = __ballot(kind == KIND_TRANSP);
+	unsigned long long bd = __ballot(kind == KIND_DIEL);
+	unsigned offset = (unsigned)__popcll(bm & lt) * (unsigned)S + (unsigned)__popcll(bt & lt) * (unsigned)(S + 1) +
+					  (unsigned)__popcll(bd & lt) * (unsigned)(S + Dn);
+	unsigned total = (unsigned)__popcll(bm) * (unsigned)S + (unsigned)__popcll(bt) * (unsigned)(S + 1) +
+					 (unsigned)__popcll(bd) * (unsigned)(S + Dn);
+	unsigned waveBase = 0;
+	if (lane == 0 && total) waveBase = atomicAdd(&cnt[0], total);
+	waveBase = __shfl(waveBase, 0, 64);
+	const unsigned childBase = waveBase + offset;
+
+	unsigned long long bdead = __ballot(dead != 0), bsh = __ballot(shaded != 0), bf = __ballot(fetches != 0);
+
+	if (nchild) {
+		if (childBase + (unsigned)nchild > nextCap) {
+			// cannot happen when the host sized the queue for the worst case; drop the subtree
+			kind = KIND_LEAF;
+			val = make_float3(0.0f, 0.0f, 0.0f);
+			nchild = 0;
+			atomicOr(&cnt[4], 1u);
+		}
+	}
+	if (nchild) {
+		// Triangle::specular (src/Triangle.cpp:121-146)
+		float np = dot3w(dx, dy, dz, nx, ny, nz);
+		float k2 = 2.0f * np;
+		float rx = dx - k2 * nx, ry = dy - k2 * ny, rz = dz - k2 * nz;
+		for (int i = 0; i < S; ++i) {
+			float ox, oy, oz;
+			scatter_offset(sc, key, 0, (uint32_t)i, ox, oy, oz);
+			float cx = rx + ox * rough, cy = ry + oy * rough, cz = rz + oz * rough;
+			nRayO[childBase + i] = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)i)));
+			nRayD[childBase + i] = make_float4(cx, cy, cz, 0.0f);
+		}
+		if (kind == KIND_DIEL) {
+			// Triangle::diffuse (src/Triangle.cpp:95-119)
+			bool keep = dot3w(dx, dy, dz, nx, ny, nz) < 0.0f;
+			float tx = keep ? nx : -nx, ty = keep ? ny : -ny, tz = keep ? nz : -nz;
+			for (int i = 0; i < Dn; ++i) {
+				float ox, oy, oz;
+				scatter_offset(sc, key, 1, (uint32_t)i, ox, oy, oz);
+				nRayO[childBase + S + i] = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)(S + i))));
+				nRayD[childBase + S + i] = make_float4(tx + ox, ty + oy, tz + oz, 0.0f);
+			}
+		}
+		else if (kind == KIND_TRANSP) {
+			// Triangle::refract (src/Triangle.cpp:149-179)
+			float dot = dot3w(dx, dy, dz, nx, ny, nz);
+			float indexRatio = dot > 0.0f ? ior : (1.0f / ior);
+			float tx = dot > 0.0f ? -nx : nx, ty = dot > 0.0f ? -ny : ny, tz = dot > 0.0f ? -nz : nz;
+			float cosineTheta = fabsf(dot);
+			float squareSine1 = 1.0f - cosineTheta * cosineTheta;
+			float squareSine2 = (indexRatio * indexRatio) * squareSine1;
+			float4 ro = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)S)));
+			if (squareSine2 > 1.0f) {
+				// total internal reflection: proportion 0, child not traced
+				flags |= FLAG_TIR;
+				scalar = 0.0f;
+				nRayO[childBase + S] = ro;
+				nRayD[childBase + S] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+			}
+			else {
+				float cosine2 = sqrtf(1.0f - squareSine2);
+				float ex = indexRatio * (dx + cosineTheta * tx) - tx * cosine2;
+				float ey = indexRatio * (dy + cosineTheta * ty) - ty * cosine2;
+				float ez = indexRatio * (dz + cosineTheta * tz) - tz * cosine2;
+				float temp = (1.0f - indexRatio) / (1.0f + indexRatio);
+				float r0 = temp * temp;
+				float squareTemp = (1.0f - cosineTheta) * (1.0f - cosineTheta);
+				float pow5 = squareTemp * squareTemp * (1.0f - cosineTheta);
+				float reflectProportion = r0 + (1.0f - r0) * pow5;
+				scalar = 1.0f - reflectProportion;
+				nRayO[childBase + S] = ro;
+				nRayD[childBase + S] = make_float4(ex, ey, ez, 0.0f);
+			}
+		}
+	}
+	if (active) {
+		A[j] = make_float4(val.x, val.y, val.z, 0.0f);
+		B[j] = make_int4((int)childBase, kind | flags, __float_as_int(scalar), 0);
+		if (flags & FLAG_TEX) C[j] = make_float4(texel.x, texel.y, texel.z, 0.0f);
+	}
+	if (lane == 0) {
+		unsigned d = (unsigned)__popcll(bdead), s = (unsigned)__popcll(bsh), f = (unsigned)__popcll(bf);
+		if (d) atomicAdd(&cnt[1], d);
+		if (s) atomicAdd(&cnt[2], s);
+		if (f) atomicAdd(&cnt[3], f);
+	}
+}
+
+// Combine step of RayTracer::color for the nodes of one level, children read from the next
+// level (src/RayTracer.cpp:177-224).  Sums start from zero and run in child order, scale
+// factors are applied after the sum, exactly as the reference does.
+__global__ __launch_bounds__(256) void k_gather(int S, int Dn, int n, float4* __restrict__ A,
+												const int4* __restrict__ B, const float4* __restrict__ C,
+												const float4* __restrict__ childA) {
+	const int j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= n) return;
+	int4 b = B[j];
+	const int kind = b.y & 0xFF;
+	if (kind == KIND_LEAF) return;
+	const float4 col = A[j];
+	const float4* ch = childA + (unsigned)b.x;
+	float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+	for (int i = 0; i < S; ++i) {
+		float4 c = ch[i];
+		sx = sx + c.x;
+		sy = sy + c.y;
+		sz = sz + c.z;
+	}
+	const float fS = (float)S;
+	float ox, oy, oz;
+	if (kind == KIND_METAL) {
+		ox = (sx * col.x) / fS;
+		oy = (sy * col.y) / fS;
+		oz = (sz * col.z) / fS;
+	}
+	else if (kind == KIND_TRANSP) {
+		sx = sx / fS;
+		sy = sy / fS;
+		sz = sz / fS;
+		const float rp = __int_as_float(b.z);
+		float4 rc = (b.y & FLAG_TIR) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : ch[S];
+		const float q = 1.0f - rp;
+		ox = rp * rc.x + q * sx;
+		oy = rp * rc.y + q * sy;
+		oz = rp * rc.z + q * sz;
+	}
+	else {
+		const float w = 0.04f / fS;
+		sx = sx * w;
+		sy = sy * w;
+		sz = sz * w;
+		float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+		for (int i = 0; i < Dn; ++i) {
+			float4 c = ch[S + i];
+			dx = dx + c.x;
+			dy = dy + c.y;
+			dz = dz + c.z;
+		}
+		const float fD = (float)Dn;
+		dx = (dx * col.x) / fD;
+		dy = (dy * col.y) / fD;
+		dz = (dz * col.z) / fD;
+		const float ad = __int_as_float(b.z);
+		ox = sx + dx * ad;
+		oy = sy + dy * ad;
+		oz = sz + dz * ad;
+		if (b.y & FLAG_TEX) {
+			float4 tx = C[j];
+			ox = ox * tx.x;
+			oy = oy * tx.y;
+			oz = oz * tx.z;
+		}
+	}
+	A[j] = make_float4(ox, oy, oz, 0.0f);
+}
+
+// accumulateImg(row,col) += (c0+c1+c2+c3) * 0.25f (src/RayTracer.cpp:242-246).  One thread per pixel.
+__global__ __launch_bounds__(256) void k_accumulate(DevScene sc, Batch b, const float4* __restrict__ A,
+													float4* __restrict__ accum) {
+	const int p = blockIdx.x * 256 + threadIdx.x;
+	if (p * 4 >= b.nSamples) return;
+	int x, y, sub;
+	if (!sample_to_pixel(sc, b, p * 4, x, y, sub)) return;
+	float tx = 0.0f, ty = 0.0f, tz = 0.0f;
+	for (int k = 0; k < 4; ++k) {
+		float4 c = A[p * 4 + k];
+		tx = tx + c.x;
+		ty = ty + c.y;
+		tz = tz + c.z;
+	}
+	float4* dst = accum + ((size_t)y * sc.width + x);
+	float4 a = *dst;
+	a.x = a.x + tx * 0.25f;
+	a.y = a.y + ty * 0.25f;
+	a.z = a.z + tz * 0.25f;
+	a.w = a.w + 0.0f * 0.25f;
+	*dst = a;
+}
+
+// Per-sample radiance export (rtx_sample_radiance): out[(y*W+x)*4+sub] = A[j].
+__global__ __launch_bounds__(256) void k_export_samples(DevScene sc, Batch b, const float4* __restrict__ A,
+														float4* __restrict__ out) {
+	const int j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= b.nSamples) return;
+	int x, y, sub;
+	if (!sample_to_pixel(sc, b, j, x, y, sub)) return;
+	out[((size_t)y * sc.width + x) * 4 + sub] = A[j];
+}
+
+// Primary-hit export: rank -> reference triangle index.
+__global__ __launch_bounds__(256) void k_export_hits(DevScene sc, Batch b, const float4* __restrict__ hits,
+													 int* __restrict__ ids, float* __restrict__ tab) {
+	const int j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= b.nSamples) return;
+	int x, y, sub;
+	if (!sample_to_pixel(sc, b, j, x, y, sub)) return;
+	float4 h = hits[j];
+	int rank = __float_as_int(h.x);
+	size_t o = ((size_t)y * sc.width + x) * 4 + sub;
+	ids[o] = rank >= 0 ? __float_as_int(sc.triHit[(size_t)rank * 4 + 3].w) : -1;
+	if (tab) {
+		tab[o * 3 + 0] = h.y;
+		tab[o * 3 + 1] = h.z;
+		tab[o * 3 + 2] = h.w;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_export_hits_linear(DevScene sc, int n, const float4* __restrict__ hits,
+															int* __restrict__ ids, float* __restrict__ tab) {
+	const int j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= n) return;
+	float4 h = hits[j];
+	int rank = __float_as_int(h.x);
+	ids[j] = rank >= 0 ? __float_as_int(sc.triHit[(size_t)rank * 4 + 3].w) : -1;
+	if (tab) {
+		tab[(size_t)j * 3 + 0] = h.y;
+		tab[(size_t)j * 3 + 1] = h.z;
+		tab[(size_t)j * 3 + 2] = h.w;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host side of the library.
+
+struct HostTri {  // include/RayTracer/Triangle.h:6-34
+	float v[3][4];
+	float n[3][4];
+	float pn[4];
+	float color[4];
+	float uv[3][2];
+	float rough, ior;
+	int32_t tex;
+	uint8_t emit, metal, transp, pad0;
+	uint8_t pad1[8];
+};
+static_assert(sizeof(HostTri) == RTX_TRIANGLE_BYTES, "triangle record");
+
+struct HostNode {  // include/RayTracer/BVH.h:35-43
+	float bmin[4], bmax[4];
+	int32_t left, right, tri, pad;
+};
+static_assert(sizeof(HostNode) == RTX_NODE_BYTES, "node record");
+
+struct TexInfo {
+	size_t offset;
+	int w, h;
+};
+
+template <typename T>
+struct DevBuf {
+	T* p = nullptr;
+	size_t n = 0;
+	hipError_t alloc(size_t count) {
+		release();
+		n = count;
+		if (!count) return hipSuccess;
+		return hipMalloc((void**)&p, count * sizeof(T));
+	}
+	void release() {
+		if (p) (void)hipFree(p);
+		p = nullptr;
+		n = 0;
+	}
+};
+
+struct EventPair {
+	hipEvent_t a, b;
+	int kind;  // 0 trace, 1 other
+};
+
+}  // namespace
+
+struct rtx_scene {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	hipStream_t ownStream = nullptr;
+	// parameters
+	bool haveParams = false, haveCamera = false, haveTris = false, haveBvh = false, haveTables = false;
+	int width = 0, height = 0, maxDepth = 1, nDiff = 1, nSpec = 1;
+	float bg[3] = {0, 0, 0};
+	uint64_t seed = 0;
+	float cam[16] = {0};
+	bool hasSky = false;
+	float skyBrightness = 1.0f;
+	int skyTex[6] = {-1, -1, -1, -1, -1, -1};
+	int tileFirst = 0, tileStride = 1, tileCount = -1;
+	uint64_t arenaLimit = 0;
+	bool instrumented = false;
+	// host copies
+	std::vector<HostTri> tris;
+	std::vector<uint8_t> texels;
+	std::vector<TexInfo> texInfo;
+	std::vector<int> rankOf;  // triangle index -> candidate rank
+	float sceneAbsMax = 0.0f;
+	int treeDepth = 0;
+	uint32_t numPairs = 0;
+	// device
+	DevBuf<float4> dPairs, dTriHit, dTriShade;
+	DevBuf<uint8_t> dTexels;
+	DevBuf<int4> dTexDesc;
+	DevBuf<float> dTables;  // cos[512] sin[512] gamma[256]
+	DevBuf<float4> dAccumOwn;
+	float4* dAccum = nullptr;  // own or external
+	bool texDirty = true;
+	DevBuf<uint8_t> arena;
+	DevBuf<unsigned> dCounts;           // 8 per level
+	DevBuf<unsigned long long> dStats;  // node tests, tri tests
+	unsigned* hCounts = nullptr;        // pinned
+	unsigned long long* hStats = nullptr;
+	std::vector<EventPair> events;
+	rtx_stats stats;
+
+	~rtx_scene() {
+		(void)hipSetDevice(device);
+		dPairs.release(); dTriHit.release(); dTriShade.release(); dTexels.release(); dTexDesc.release();
+		dTables.release(); dAccumOwn.release(); arena.release(); dCounts.release(); dStats.release();
+		if (hCounts) (void)hipHostFree(hCounts);
+		if (hStats) (void)hipHostFree(hStats);
+		for (auto& e : events) {
+			(void)hipEventDestroy(e.a);
+			(void)hipEventDestroy(e.b);
+		}
+		if (ownStream) (void)hipStreamDestroy(ownStream);
+	}
+};
+
+namespace {
+
+constexpr int MAX_DEPTH = 15;
+constexpr int CNT_STRIDE = 8;
+
+int num_tiles(const rtx_scene* s) {
+	int tx = (s->width + TILE - 1) / TILE, ty = (s->height + TILE - 1) / TILE;
+	return tx * ty;
+}
+
+// Number of tiles in this scene's share: first, first+stride, ... below the tile total.
+int tile_slots(const rtx_scene* s) {
+	int total = num_tiles(s);
+	if (s->tileFirst >= total) return 0;
+	int avail = (total - s->tileFirst + s->tileStride - 1) / s->tileStride;
+	if (s->tileCount >= 0 && s->tileCount < avail) avail = s->tileCount;
+	return avail;
+}
+
+DevScene make_dev_scene(const rtx_scene* s) {
+	DevScene d;
+	std::memset(&d, 0, sizeof(d));
+	d.pairs = s->dPairs.p;
+	d.triHit = s->dTriHit.p;
+	d.triShade = s->dTriShade.p;
+	d.texels = s->dTexels.p;
+	d.texDesc = s->dTexDesc.p;
+	d.cosT = s->dTables.p;
+	d.sinT = s->dTables.p + 512;
+	d.gammaT = s->dTables.p + 1024;
+	d.camO = make_float4(s->cam[0], s->cam[1], s->cam[2], s->cam[3]);
+	d.camLUC = make_float4(s->cam[4], s->cam[5], s->cam[6], s->cam[7]);
+	d.camRS = make_float4(s->cam[8], s->cam[9], s->cam[10], s->cam[11]);
+	d.camDS = make_float4(s->cam[12], s->cam[13], s->cam[14], s->cam[15]);
+	d.bg = make_float4(s->bg[0], s->bg[1], s->bg[2], 0.0f);
+	d.width = s->width;
+	d.height = s->height;
+	d.maxDepth = s->maxDepth;
+	d.nDiff = s->nDiff;
+	d.nSpec = s->nSpec;
+	d.hasSky = s->hasSky ? 1 : 0;
+	d.skyBrightness = s->skyBrightness;
+	for (int i = 0; i < 6; ++i) d.skyTex[i] = s->skyTex[i];
+	// same folding of the 64-bit seed as the CPU side of the RNG specification
+	auto mix = [](uint32_t h, uint32_t v) {
+		h = (h + 0x7F4A7C15u) ^ (v * 0x9E3779B1u);
+		h ^= h >> 16;
+		h *= 0x85EBCA6Bu;
+		h ^= h >> 13;
+		h *= 0xC2B2AE35u;
+		h ^= h >> 16;
+		return h;
+	};
+	d.seedKey = mix((uint32_t)s->seed, (uint32_t)(s->seed >> 32));
+	d.sceneAbsMax = s->sceneAbsMax;
+	d.tilesX = (s->width + TILE - 1) / TILE;
+	return d;
+}
+
+int upload_textures(rtx_scene* s) {
+	if (!s->texDirty) return RTX_OK;
+	HIPCHK(s->dTexels.alloc(std::max<size_t>(s->texels.size(), 16)));
+	if (!s->texels.empty())
+		HIPCHK(hipMemcpy(s->dTexels.p, s->texels.data(), s->texels.size(), hipMemcpyHostToDevice));
+	std::vector<int4> desc(std::max<size_t>(s->texInfo.size(), 1));
+	for (size_t i = 0; i < s->texInfo.size(); ++i) {
+		if (s->texInfo[i].offset > 0x7FFFFFFFull) return fail(RTX_ERR_ARG, "texture data beyond 2 GiB");
+		desc[i] = make_int4((int)s->texInfo[i].offset, s->texInfo[i].w, s->texInfo[i].h, 0);
+	}
+	HIPCHK(s->dTexDesc.alloc(desc.size()));
+	HIPCHK(hipMemcpy(s->dTexDesc.p, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
+	s->texDirty = false;
+	return RTX_OK;
+}
+
+int ensure_ready(rtx_scene* s, bool needCamera) {
+	if (!s->haveParams) return fail(RTX_ERR_STATE, "rtx_scene_set_params has not been called");
+	if (needCamera && !s->haveCamera) return fail(RTX_ERR_STATE, "rtx_scene_set_camera has not been called");
+	if (!s->haveTris) return fail(RTX_ERR_STATE, "rtx_scene_set_triangles has not been called");
+	if (!s->haveBvh) return fail(RTX_ERR_STATE, "rtx_scene_set_bvh has not been called");
+	if (!s->haveTables) return fail(RTX_ERR_STATE, "rtx_scene_set_tables has not been called");
+	HIPCHK(hipSetDevice(s->device));
+	const int ntex = (int)s->texInfo.size();
+	for (const HostTri& t : s->tris)
+		if (t.tex >= ntex) return fail(RTX_ERR_ARG, "a triangle refers to a texture id that was never added");
+	if (s->hasSky)
+		for (int i = 0; i < 6; ++i)
+			if (s->skyTex[i] < 0 || s->skyTex[i] >= ntex) return fail(RTX_ERR_ARG, "skybox texture id out of range");
+	int rc = upload_textures(s);
+	if (rc) return rc;
+	if (!s->dAccum) {
+		HIPCHK(s->dAccumOwn.alloc((size_t)s->width * s->height));
+		HIPCHK(hipMemset(s->dAccumOwn.p, 0, (size_t)s->width * s->height * sizeof(float4)));
+		s->dAccum = s->dAccumOwn.p;
+	}
+	if (!s->stream) {
+		if (!s->ownStream) HIPCHK(hipStreamCreateWithFlags(&s->ownStream, hipStreamNonBlocking));
+		s->stream = s->ownStream;
+	}
+	if (!s->dCounts.p) {
+		HIPCHK(s->dCounts.alloc((MAX_DEPTH + 2) * CNT_STRIDE));
+		HIPCHK(s->dStats.alloc(2));
+		HIPCHK(hipHostMalloc((void**)&s->hCounts, (MAX_DEPTH + 2) * CNT_STRIDE * sizeof(unsigned), hipHostMallocDefault));
+		HIPCHK(hipHostMalloc((void**)&s->hStats, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+	}
+	return RTX_OK;
+}
+
+// Worst-case queue bytes per primary sample: every node spawns the maximum number of
+// children at every level.  Persistent per node: A (16) + B (16) + C (16); transient, two
+// ping-pong sets sized for the widest level: origin (16) + direction (16) + hit (16).
+constexpr size_t NODE_BYTES = 48, RAY_BYTES = 48;
+
+double worst_bytes_per_sample(const rtx_scene* s) {
+	double bmax = (double)std::max(s->nSpec + s->nDiff, s->nSpec + 1);
+	double sum = 0.0, pw = 1.0;
+	for (int d = 0; d <= s->maxDepth; ++d) {
+		sum += pw;
+		if (d < s->maxDepth) pw *= bmax;
+	}
+	return sum * NODE_BYTES + 2.0 * pw * RAY_BYTES;
+}
+
+struct EventScope {
+	rtx_scene* s;
+	size_t idx;
+};
+
+int begin_event(rtx_scene* s, int kind, size_t& idx) {
+	EventPair e;
+	HIPCHK(hipEventCreate(&e.a));
+	HIPCHK(hipEventCreate(&e.b));
+	e.kind = kind;
+	s->events.push_back(e);
+	idx = s->events.size() - 1;
+	HIPCHK(hipEventRecord(e.a, s->stream));
+	return RTX_OK;
+}
+int end_event(rtx_scene* s, size_t idx) {
+	HIPCHK(hipEventRecord(s->events[idx].b, s->stream));
+	return RTX_OK;
+}
+// After a stream sync: fold event durations into the stats and recycle the events.
+int harvest_events(rtx_scene* s) {
+	for (auto& e : s->events) {
+		float ms = 0.0f;
+		HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+		if (e.kind == 0) {
+			s->stats.trace_ms += ms;
+			s->stats.trace_launches++;
+		}
+		else if (e.kind == 1)
+			s->stats.shade_ms += ms;
+		else
+			s->stats.total_ms += ms;
+		(void)hipEventDestroy(e.a);
+		(void)hipEventDestroy(e.b);
+	}
+	s->events.clear();
+	return RTX_OK;
+}
+
+template <bool ANYHIT, bool EXH>
+int launch_trace_t(rtx_scene* s, const DevScene& d, const float4* ro, const float4* rd, float4* hits, int n) {
+	dim3 grid((n + TRACE_THREADS - 1) / TRACE_THREADS), block(TRACE_THREADS);
+	const bool deep = s->treeDepth > 24;
+	const bool st = s->instrumented;
+	unsigned long long* stats = s->dStats.p;
+#define RTX_LAUNCH(STK, ST) \
+	hipLaunchKernelGGL((k_trace<STK, ANYHIT, EXH, ST>), grid, block, 0, s->stream, d, ro, rd, hits, n, stats)
+	if (deep) {
+		if (st) RTX_LAUNCH(33, true); else RTX_LAUNCH(33, false);
+	}
+	else {
+		if (st) RTX_LAUNCH(25, true); else RTX_LAUNCH(25, false);
+	}
+#undef RTX_LAUNCH
+	HIPCHK(hipGetLastError());
+	return RTX_OK;
+}
+
+int launch_trace(rtx_scene* s, const DevScene& d, bool anyhit, bool exhaustive, const float4* ro, const float4* rd,
+				 float4* hits, int n) {
+	if (n <= 0) return RTX_OK;
+	size_t ev;
+	int rc = begin_event(s, 0, ev);
+	if (rc) return rc;
+	if (exhaustive)
+		rc = launch_trace_t<false, true>(s, d, ro, rd, hits, n);
+	else if (anyhit)
+		rc = launch_trace_t<true, false>(s, d, ro, rd, hits, n);
+	else
+		rc = launch_trace_t<false, false>(s, d, ro, rd, hits, n);
+	if (rc) return rc;
+	return end_event(s, ev);
+}
+
+int ensure_arena(rtx_scene* s, size_t want) {
+	if (s->arena.n >= want) return RTX_OK;
+	s->arena.release();
+	hipError_t e = s->arena.alloc(want);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		return fail(RTX_ERR_MEMORY, "cannot allocate the work arena (" + std::to_string(want >> 20) + " MiB)");
+	}
+	return RTX_OK;
+}
+
+struct Bump {
+	uint8_t* base;
+	size_t cap, lo, hi;  // persistent grows from lo, transient sets are carved at fixed offsets from hi
+	void* take(size_t bytes) {
+		bytes = (bytes + 255) & ~(size_t)255;
+		if (lo + bytes > hi) return nullptr;
+		void* p = base + lo;
+		lo += bytes;
+		return p;
+	}
+};
+
+// mode: 0 = accumulate, 1 = export per-sample radiance to dOut (float4 per sample),
+//       2 = primary hits only (hitMode 0 culled / 1 exhaustive) exported to dIds/dTab.
+int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* dOut, int* dIds, float* dTab) {
+	const DevScene d = make_dev_scene(s);
+	const int slots = tile_slots(s);
+	const long long totalBlocks = (long long)slots * BLOCKS_PER_TILE;
+	if (totalBlocks == 0) return RTX_OK;
+	const int levels = (mode == 2) ? 0 : s->maxDepth;
+	const int bmax = std::max(s->nSpec + s->nDiff, s->nSpec + 1);
+
+	// batch size from the arena budget
+	double perSample = (mode == 2) ? (double)(NODE_BYTES + RAY_BYTES) : worst_bytes_per_sample(s);
+	size_t freeB = 0, totalB = 0;
+	HIPCHK(hipMemGetInfo(&freeB, &totalB));
+	size_t budget = s->arenaLimit ? (size_t)s->arenaLimit : (size_t)((double)(freeB + s->arena.n) * 0.6);
+	double needAll = perSample * (double)totalBlocks * SAMPLES_PER_BLOCK + (double)(MAX_DEPTH + 4) * 4096;
+	size_t want = (size_t)std::min((double)budget, needAll);
+	long long blocksPerBatch = (long long)(((double)want - (double)(MAX_DEPTH + 4) * 4096) / (perSample * SAMPLES_PER_BLOCK));
+	if (blocksPerBatch < 1) {
+		blocksPerBatch = 1;
+		want = (size_t)(perSample * SAMPLES_PER_BLOCK) + (MAX_DEPTH + 4) * 4096;
+	}
+	if (blocksPerBatch > totalBlocks) blocksPerBatch = totalBlocks;
+	// keep sample indices inside int32
+	const long long maxBlocksInt = (long long)(0x7FFFFF00ll / SAMPLES_PER_BLOCK);
+	long long widest = 1;
+	for (int i = 0; i < levels; ++i) widest *= bmax;
+	if (blocksPerBatch * widest > maxBlocksInt) blocksPerBatch = std::max<long long>(1, maxBlocksInt / widest);
+	int rc = ensure_arena(s, want);
+	if (rc) return rc;
+
+	for (long long g0 = 0; g0 < totalBlocks; g0 += blocksPerBatch) {
+		const long long nb = std::min(blocksPerBatch, totalBlocks - g0);
+		Batch b;
+		b.g0 = (int)g0;
+		b.nSamples = (int)(nb * SAMPLES_PER_BLOCK);
+		b.tileFirst = s->tileFirst;
+		b.tileStride = s->tileStride;
+		s->stats.chunks++;
+
+		// arena carve-up: transient ray sets at the top, node arrays bump-allocated from the bottom
+		size_t widestCap = (size_t)b.nSamples;
+		for (int i = 0; i < levels; ++i) widestCap *= (size_t)bmax;
+		const size_t setBytes = ((widestCap * 16 + 255) & ~(size_t)255);
+		Bump bump{s->arena.p, s->arena.n, 0, s->arena.n};
+		if (6 * setBytes > bump.cap) return fail(RTX_ERR_MEMORY, "work arena too small for one pixel block");
+		bump.hi = bump.cap - 6 * setBytes;
+		float4* rayO[2] = {(float4*)(bump.base + bump.hi), (float4*)(bump.base + bump.hi + 3 * setBytes)};
+		float4* rayD[2] = {(float4*)(bump.base + bump.hi + setBytes), (float4*)(bump.base + bump.hi + 4 * setBytes)};
+		float4* hit[2] = {(float4*)(bump.base + bump.hi + 2 * setBytes), (float4*)(bump.base + bump.hi + 5 * setBytes)};
+
+		HIPCHK(hipMemsetAsync(s->dCounts.p, 0, (MAX_DEPTH + 2) * CNT_STRIDE * sizeof(unsigned), s->stream));
+		size_t ev;
+		rc = begin_event(s, 1, ev);
+		if (rc) return rc;
+		hipLaunchKernelGGL(k_raygen, dim3((b.nSamples + 255) / 256), dim3(256), 0, s->stream, d, b, frame, rayO[0], rayD[0]);
+		HIPCHK(hipGetLastError());
+		rc = end_event(s, ev);
+		if (rc) return rc;
+
+		if (mode == 2) {
+			rc = launch_trace(s, d, false, hitMode == 1, rayO[0], rayD[0], hit[0], b.nSamples);
+			if (rc) return rc;
+			hipLaunchKernelGGL(k_export_hits, dim3((b.nSamples + 255) / 256), dim3(256), 0, s->stream, d, b, hit[0], dIds, dTab);
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipStreamSynchronize(s->stream));
+			s->stats.rays_per_level[0] += (uint64_t)b.nSamples;
+			continue;
+		}
+
+		float4* A[MAX_DEPTH + 1];
+		int4* B[MAX_DEPTH + 1];
+		float4* C[MAX_DEPTH + 1];
+		int count[MAX_DEPTH + 2];
+		count[0] = b.nSamples;
+		int last = 0;
+		for (int lv = 0; lv <= s->maxDepth; ++lv) {
+			const int n = count[lv];
+			last = lv;
+			A[lv] = (float4*)bump.take((size_t)n * 16);
+			B[lv] = (int4*)bump.take((size_t)n * 16);
+			C[lv] = (float4*)bump.take((size_t)n * 16);
+			if (!A[lv] || !B[lv] || !C[lv]) return fail(RTX_ERR_MEMORY, "work arena exhausted (internal sizing error)");
+			const int cur = lv & 1, nxt = cur ^ 1;
+			rc = launch_trace(s, d, lv == s->maxDepth, false, rayO[cur], rayD[cur], hit[cur], n);
+			if (rc) return rc;
+			unsigned* cnt = s->dCounts.p + (size_t)(lv + 1) * CNT_STRIDE;
+			const unsigned nextCap = (unsigned)std::min<size_t>((size_t)n * (size_t)bmax, widestCap);
+			rc = begin_event(s, 1, ev);
+			if (rc) return rc;
+			hipLaunchKernelGGL(k_shade, dim3((n + 255) / 256), dim3(256), 0, s->stream, d, lv, rayO[cur], rayD[cur],
+							   hit[cur], n, A[lv], B[lv], C[lv], rayO[nxt], rayD[nxt], cnt, nextCap);
+			HIPCHK(hipGetLastError());
+			rc = end_event(s, ev);
+			if (rc) return rc;
+			HIPCHK(hipMemcpyAsync(s->hCounts + (size_t)(lv + 1) * CNT_STRIDE, cnt, CNT_STRIDE * sizeof(unsigned),
+								  hipMemcpyDeviceToHost, s->stream));
+			HIPCHK(hipStreamSynchronize(s->stream));
+			const unsigned* hc = s->hCounts + (size_t)(lv + 1) * CNT_STRIDE;
+			if (hc[4]) return fail(RTX_ERR_MEMORY, "child queue overflow (internal sizing error)");
+			s->stats.rays_per_level[lv] += (uint64_t)n - hc[1];
+			s->stats.rays += (uint64_t)n - hc[1];
+			s->stats.shaded_hits += hc[2];
+			s->stats.texture_fetches += hc[3];
+			count[lv + 1] = (int)hc[0];
+			if (lv == s->maxDepth || hc[0] == 0) break;
+		}
+		rc = begin_event(s, 1, ev);
+		if (rc) return rc;
+		for (int lv = last - 1; lv >= 0; --lv) {
+			const int n = count[lv];
+			hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->nSpec, s->nDiff, n, A[lv],
+							   B[lv], C[lv], A[lv + 1]);
+			HIPCHK(hipGetLastError());
+		}
+		const int npix = b.nSamples / 4;
+		if (mode == 0)
+			hipLaunchKernelGGL(k_accumulate, dim3((npix + 255) / 256), dim3(256), 0, s->stream, d, b, A[0], s->dAccum);
+		else
+			hipLaunchKernelGGL(k_export_samples, dim3((b.nSamples + 255) / 256), dim3(256), 0, s->stream, d, b, A[0], dOut);
+		HIPCHK(hipGetLastError());
+		rc = end_event(s, ev);
+		if (rc) return rc;
+		HIPCHK(hipStreamSynchronize(s->stream));
+		rc = harvest_events(s);
+		if (rc) return rc;
+	}
+	HIPCHK(hipStreamSynchronize(s->stream));
+	return harvest_events(s);
+}
+
+int finish_stats(rtx_scene* s) {
+	if (s->instrumented) {
+		HIPCHK(hipMemcpy(s->hStats, s->dStats.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		s->stats.node_tests = s->hStats[0];
+		s->stats.tri_tests = s->hStats[1];
+	}
+	return RTX_OK;
+}
+
+int begin_call(rtx_scene* s) {
+	std::memset(&s->stats, 0, sizeof(s->stats));
+	if (s->instrumented) HIPCHK(hipMemsetAsync(s->dStats.p, 0, 2 * sizeof(unsigned long long), s->stream));
+	return RTX_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+
+RTX_API const char* rtx_last_error(void) { return g_err.c_str(); }
+
+RTX_API int rtx_device_count(void) {
+	int n = 0;
+	HIPCHK(hipGetDeviceCount(&n));
+	return n;
+}
+
+RTX_API int rtx_scene_create(rtx_scene** out, int device) {
+	if (!out) return fail(RTX_ERR_ARG, "out is null");
+	int n = 0;
+	HIPCHK(hipGetDeviceCount(&n));
+	if (device < 0 || device >= n) return fail(RTX_ERR_ARG, "no such HIP device");
+	HIPCHK(hipSetDevice(device));
+	rtx_scene* s = new (std::nothrow) rtx_scene();
+	if (!s) return fail(RTX_ERR_MEMORY, "out of host memory");
+	s->device = device;
+	std::memset(&s->stats, 0, sizeof(s->stats));
+	*out = s;
+	return RTX_OK;
+}
+
+RTX_API int rtx_scene_destroy(rtx_scene* s) {
+	delete s;
+	return RTX_OK;
+}
+
+RTX_API int rtx_scene_set_stream(rtx_scene* s, void* hip_stream) {
+	if (!s) return fail(RTX_ERR_ARG, "scene is null");
+	s->stream = (hipStream_t)hip_stream;
+	return RTX_OK;
+}
+
+RTX_API int rtx_scene_set_params(rtx_scene* s, int width, int height, int max_depth, int n_diffuse, int n_specular,
+								 const float background_rgb[3], uint64_t seed) {
+	if (!s || !background_rgb) return fail(RTX_ERR_ARG, "null argument");
+	if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28))
+		return fail(RTX_ERR_ARG, "image size out of range");
+	if (max_depth < 1 || max_depth > MAX_DEPTH) return fail(RTX_ERR_ARG, "max_depth must be in 1..15");
+	if (n_diffuse < 1 || n_diffuse > 64 || n_specular < 1 || n_specular > 64)
+		return fail(RTX_ERR_ARG, "ray numbers must be in 1..64");
+	if (s->haveParams && (width != s->width || height != s->height)) {
+		HIPCHK(hipSetDevice(s->device));
+		s->dAccumOwn.release();
+		if (s->dAccum && s->dAccum == s->dAccumOwn.p) s->dAccum = nullptr;
+		s->dAccum = nullptr;
+	}
+	s->width = width;
+	s->height = height;
+	s->maxDepth = max_depth;
+	s->nDiff = n_diffuse;
+	s->nSpec = n_specular;
+	for (int i = 0; i < 3; ++i) s->bg[i] = background_rgb[i];
+	s->seed = seed;
+	s->haveParams = true;
+	return RTX_OK;
+}
+
+RTX_API int rtx_scene_set_camera(rtx_scene* s, const float origin[4], const float left_up_corner[4],
+								 const float right_step[4], const float down_step[4]) {
+	if (!s || !origin || !left_up_corner || !right_step || !down_step) return fail(RTX_ERR_ARG, "null argument");
+	std::memcpy(s->cam + 0, origin, 16);
+	std::memcpy(s->cam + 4, left_up_corner, 16);
+	std::memcpy(s->cam + 8, right_step, 16);
+	std::memcpy(s->cam + 12, down_step, 16);
+	s->haveCamera = true;
+	return RTX_OK;
+}
+
+RTX_API int rtx_scene_set_triangles(rtx_scene* s, const void* triangles, uint32_t n) {
+	if (!s || (!triangles && n)) return fail(RTX_ERR_ARG, "null argument");
+	if (n > (1u << 30)) return fail(RTX_ERR_ARG, "too many triangles");
+	s->tris.resize(n);
+	if (n) std::memcpy((void*)s->tris.data(), triangles, (size_t)n * sizeof(HostTri));
+	float amax = 0.0f;
+	for (const HostTri& t : s->tris) {
+		for (int k = 0; k < 3; ++k) {
+			if (!(t.v[k][3] == 0.0f) || !(t.n[k][3] == 0.0f))
+				return fail(RTX_ERR_ARG, "triangle w lanes must be zero, as the reference constructs them");
+			for (int c = 0; c < 3; ++c) {
+				float a = std::fabs(t.v[k][c]);
+				if (!(a <= FLT_MAX)) return fail(RTX_ERR_ARG, "non-finite vertex position");
+				amax = std::max(amax, a);
+			}
+		}
+		if (!(t.pn[3] == 0.0f)) return fail(RTX_ERR_ARG, "triangle w lanes must be zero, as the reference constructs them");
+		if (t.tex < -1) return fail(RTX_ERR_ARG, "texture index below -1");
+	}
+	s->sceneAbsMax = amax;
+	s->haveTris = true;
+	s->haveBvh = false;
+	return RTX_OK;
+}
+
+RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n) {
+	if (!s || !linear_nodes) return fail(RTX_ERR_ARG, "null argument");
+	if (!s->haveTris) return fail(RTX_ERR_STATE, "rtx_scene_set_triangles must come first");
+	if (n == 0) return fail(RTX_ERR_ARG, "a tree has at least its root");
+	const HostNode* N = (const HostNode*)linear_nodes;
+	const uint32_t ntri = (uint32_t)s->tris.size();
+
+	// Pass 1: the reference's own visiting order with every box hit (src/BVH.cpp:170-189: left
+	// pushed first, right popped first) numbers the leaves; that number is the tie-break rank.
+	std::vector<int> rankOf(ntri, -1);
+	std::vector<int> depthOf(n, 0);
+	std::vector<uint8_t> seen(n, 0);
+	std::vector<int> st;
+	st.push_back(0);
+	int nextRank = 0, maxDepth = 0;
+	size_t visited = 0;
+	while (!st.empty()) {
+		int i = st.back();
+		st.pop_back();
+		if (seen[i]) return fail(RTX_ERR_ARG, "node reachable twice: not a tree");
+		seen[i] = 1;
+		++visited;
+		const HostNode& nd = N[i];
+		maxDepth = std::max(maxDepth, depthOf[i]);
+		if (nd.tri >= 0) {
+			if ((uint32_t)nd.tri >= ntri) return fail(RTX_ERR_ARG, "leaf refers to a triangle out of range");
+			if (rankOf[nd.tri] != -1) return fail(RTX_ERR_ARG, "triangle referenced by two leaves");
+			rankOf[nd.tri] = nextRank++;
+			continue;
+		}
+		for (int c : {nd.left, nd.right}) {
+			if (c > 0) {
+				if ((uint32_t)c >= n) return fail(RTX_ERR_ARG, "child index out of range");
+				depthOf[c] = depthOf[i] + 1;
+				st.push_back(c);
+			}
+		}
+	}
+	if ((uint32_t)nextRank != ntri) return fail(RTX_ERR_ARG, "tree does not hold every triangle exactly once");
+	if (maxDepth > 32) return fail(RTX_ERR_ARG, "tree deeper than 32 levels");
+
+	// Pass 2: pair records.  Pair 0 holds the root alone; every interior node with at least one
+	// child owns one pair, numbered breadth-first.
+	std::vector<int> pairOf(n, 0);
+	std::vector<int> order;  // interior nodes owning a pair, in pair order (pair index = position + 1)
+	order.reserve(n / 2 + 1);
+	{
+		std::vector<int> q;
+		q.push_back(0);
+		for (size_t h = 0; h < q.size(); ++h) {
+			int i = q[h];
+			const HostNode& nd = N[i];
+			if (nd.tri >= 0) continue;
+			if (nd.left > 0 || nd.right > 0) {
+				order.push_back(i);
+				pairOf[i] = (int)order.size();
+				if (nd.left > 0) q.push_back(nd.left);
+				if (nd.right > 0) q.push_back(nd.right);
+			}
+		}
+	}
+	auto code_of = [&](int c) -> int {
+		if (c <= 0) return 0;
+		if (N[c].tri >= 0) return ~rankOf[N[c].tri];
+		return pairOf[c];  // 0 when the interior node has no children: nothing below it
+	};
+	const size_t npairs = order.size() + 1;
+	std::vector<float4> pairs(npairs * 4);
+	auto put = [&](size_t p, int side, int node, int code) {
+		const HostNode& nd = N[node];
+		pairs[p * 4 + side * 2 + 0] = make_float4(nd.bmin[0], nd.bmin[1], nd.bmin[2], 0.0f);
+		pairs[p * 4 + side * 2 + 1] = make_float4(nd.bmax[0], nd.bmax[1], nd.bmax[2], 0.0f);
+		std::memcpy(&pairs[p * 4 + side * 2 + 0].w, &code, 4);
+	};
+	for (auto& q : pairs) q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	{
+		int rootCode = N[0].tri >= 0 ? ~rankOf[N[0].tri] : pairOf[0];
+		put(0, 0, 0, rootCode);
+	}
+	for (size_t k = 0; k < order.size(); ++k) {
+		const HostNode& nd = N[order[k]];
+		if (nd.left > 0) put(k + 1, 0, nd.left, code_of(nd.left));
+		if (nd.right > 0) put(k + 1, 1, nd.right, code_of(nd.right));
+	}
+
+	// Triangle records in rank order.
+	std::vector<float4> th((size_t)std::max<uint32_t>(ntri, 1) * 4), ts((size_t)std::max<uint32_t>(ntri, 1) * 6);
+	for (uint32_t i = 0; i < ntri; ++i) {
+		const HostTri& t = s->tris[i];
+		const size_t r = (size_t)rankOf[i];
+		const float* v0 = t.v[0];
+		const float* v1 = t.v[1];
+		const float* v2 = t.v[2];
+		float a1[3], a2[3];
+		for (int c = 0; c < 3; ++c) {
+			a1[c] = v0[c] - v2[c];  // src/Triangle.cpp:31
+			a2[c] = v1[c] - v2[c];  // src/Triangle.cpp:32
+		}
+		float idf;
+		int32_t id = (int32_t)i;
+		std::memcpy(&idf, &id, 4);
+		th[r * 4 + 0] = make_float4(t.pn[0], t.pn[1], t.pn[2], v0[0]);
+		th[r * 4 + 1] = make_float4(v0[1], v0[2], v2[0], v2[1]);
+		th[r * 4 + 2] = make_float4(v2[2], a1[0], a1[1], a1[2]);
+		th[r * 4 + 3] = make_float4(a2[0], a2[1], a2[2], idf);
+		int32_t flags = (t.emit ? TRI_EMIT : 0) | (t.metal ? TRI_METAL : 0) | (t.transp ? TRI_TRANSP : 0);
+		float texf, flagf;
+		std::memcpy(&texf, &t.tex, 4);
+		std::memcpy(&flagf, &flags, 4);
+		ts[r * 6 + 0] = make_float4(t.n[0][0], t.n[0][1], t.n[0][2], t.color[0]);
+		ts[r * 6 + 1] = make_float4(t.n[1][0], t.n[1][1], t.n[1][2], t.color[1]);
+		ts[r * 6 + 2] = make_float4(t.n[2][0], t.n[2][1], t.n[2][2], t.color[2]);
+		ts[r * 6 + 3] = make_float4(t.uv[0][0], t.uv[0][1], t.uv[1][0], t.uv[1][1]);
+		ts[r * 6 + 4] = make_float4(t.uv[2][0], t.uv[2][1], t.rough, t.ior);
+		ts[r * 6 + 5] = make_float4(texf, flagf, idf, 0.0f);
+	}
+
+	HIPCHK(hipSetDevice(s->device));
+	HIPCHK(s->dPairs.alloc(pairs.size()));
+	HIPCHK(hipMemcpy(s->dPairs.p, pairs.data(), pairs.size() * sizeof(float4), hipMemcpyHostToDevice));
+	HIPCHK(s->dTriHit.alloc(th.size()));
+	HIPCHK(hipMemcpy(s->dTriHit.p, th.data(), th.size() * sizeof(float4), hipMemcpyHostToDevice));
+	HIPCHK(s->dTriShade.alloc(ts.size()));
+	HIPCHK(hipMemcpy(s->dTriShade.p, ts.data(), ts.size() * sizeof(float4), hipMemcpyHostToDevice));
+	s->rankOf.swap(rankOf);
+	s->numPairs = (uint32_t)npairs;
+	s->treeDepth = maxDepth + 1;  // + the root-only pair
+	s->haveBvh = true;
+	return RTX_OK;
+}
+
+RTX_API int rtx_scene_add_texture(rtx_scene* s, const uint8_t* rgb, int width, int height) {
+	if (!s || !rgb) return fail(RTX_ERR_ARG, "null argument");
+	if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28)) return fail(RTX_ERR_ARG, "texture size out of range");
+	TexInfo ti;
+	ti.offset = (s->texels.size() + 15) & ~(size_t)15;
+	ti.w = width;
+	ti.h = height;
+	s->texels.resize(ti.offset + (size_t)width * height * 3);
+	std::memcpy(s->texels.data() + ti.offset, rgb, (size_t)width * height * 3);
+	s->texInfo.push_back(ti);
+	s->texDirty = true;
+	return (int)s->texInfo.size() - 1;
+}
+
+RTX_API int rtx_scene_set_skybox(rtx_scene* s, float brightness, const int texture_ids[6]) {
+	if (!s || !texture_ids) return fail(RTX_ERR_ARG, "null argument");
+	s->hasSky = true;
+	s->skyBrightness = brightness;
+	for (int i = 0; i < 6; ++i) s->skyTex[i] = texture_ids[i];
+	return RTX_OK;
+}
+
+RTX_API int rtx_scene_set_tables(rtx_scene* s, const float cos512[512], const float sin512[512], const float gamma256[256]) {
+	if (!s || !cos512 || !sin512 || !gamma256) return fail(RTX_ERR_ARG, "null argument");
+	HIPCHK(hipSetDevice(s->device));
+	std::vector<float> t(1280);
+	std::memcpy(t.data(), cos512, 2048);
+	std::memcpy(t.data() + 512, sin512, 2048);
+	std::memcpy(t.data() + 1024, gamma256, 1024);
+	HIPCHK(s->dTables.alloc(1280));
+	HIPCHK(hipMemcpy(s->dTables.p, t.data(), 1280 * sizeof(float), hipMemcpyHostToDevice));
+	s->haveTables = true;
+	return RTX_OK;
+}
+
+RTX_API int rtx_scene_set_tiles(rtx_scene* s, int first, int stride, int count) {
+	if (!s) return fail(RTX_ERR_ARG, "scene is null");
+	if (first < 0 || stride < 1) return fail(RTX_ERR_ARG, "first >= 0 and stride >= 1 required");
+	s->tileFirst = first;
+	s->tileStride = stride;
+	s->tileCount = count;
+	return RTX_OK;
+}
+
+RTX_API int rtx_scene_set_arena_bytes(rtx_scene* s, uint64_t bytes) {
+	if (!s) return fail(RTX_ERR_ARG, "scene is null");
+	s->arenaLimit = bytes;
+	return RTX_OK;
+}
+
+RTX_API int rtx_scene_set_accum_device(rtx_scene* s, void* device_rgba) {
+	if (!s) return fail(RTX_ERR_ARG, "scene is null");
+	s->dAccum = device_rgba ? (float4*)device_rgba : s->dAccumOwn.p;
+	return RTX_OK;
+}
+
+RTX_API int rtx_accum_reset(rtx_scene* s) {
+	if (!s) return fail(RTX_ERR_ARG, "scene is null");
+	int rc = ensure_ready(s, false);
+	if (rc) return rc;
+	HIPCHK(hipMemsetAsync(s->dAccum, 0, (size_t)s->width * s->height * sizeof(float4), s->stream));
+	HIPCHK(hipStreamSynchronize(s->stream));
+	return RTX_OK;
+}
+
+RTX_API int rtx_render_frames(rtx_scene* s, uint32_t first_frame, uint32_t n_frames) {
+	if (!s) return fail(RTX_ERR_ARG, "scene is null");
+	int rc = ensure_ready(s, true);
+	if (rc) return rc;
+	rc = begin_call(s);
+	if (rc) return rc;
+	size_t evTotal;
+	rc = begin_event(s, 2, evTotal);
+	if (rc) return rc;
+	// the total-time event pair must survive the per-batch harvests: park it
+	EventPair total = s->events.back();
+	s->events.pop_back();
+	for (uint32_t f = 0; f < n_frames; ++f) {
+		rc = render_batches(s, first_frame + f, 0, 0, nullptr, nullptr, nullptr);
+		if (rc) {
+			(void)hipEventDestroy(total.a);
+			(void)hipEventDestroy(total.b);
+			return rc;
+		}
+	}
+	s->events.push_back(total);
+	rc = end_event(s, s->events.size() - 1);
+	if (rc) return rc;
+	HIPCHK(hipStreamSynchronize(s->stream));
+	rc = harvest_events(s);
+	if (rc) return rc;
+	return finish_stats(s);
+}
+
+RTX_API int rtx_accum_read(rtx_scene* s, float* host_rgba) {
+	if (!s || !host_rgba) return fail(RTX_ERR_ARG, "null argument");
+	int rc = ensure_ready(s, false);
+	if (rc) return rc;
+	HIPCHK(hipMemcpyAsync(host_rgba, s->dAccum, (size_t)s->width * s->height * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+	HIPCHK(hipStreamSynchronize(s->stream));
+	return RTX_OK;
+}
+
+RTX_API int rtx_accum_write(rtx_scene* s, const float* host_rgba) {
+	if (!s || !host_rgba) return fail(RTX_ERR_ARG, "null argument");
+	int rc = ensure_ready(s, false);
+	if (rc) return rc;
+	HIPCHK(hipMemcpyAsync(s->dAccum, host_rgba, (size_t)s->width * s->height * sizeof(float4), hipMemcpyHostToDevice, s->stream));
+	HIPCHK(hipStreamSynchronize(s->stream));
+	return RTX_OK;
+}
+
+RTX_API int rtx_primary_hits(rtx_scene* s, int mode, int32_t* tri_ids, float* t_alpha_beta) {
+	if (!s || !tri_ids) return fail(RTX_ERR_ARG, "null argument");
+	if (mode != 0 && mode != 1) return fail(RTX_ERR_ARG, "mode must be 0 or 1");
+	int rc = ensure_ready(s, true);
+	if (rc) return rc;
+	rc = begin_call(s);
+	if (rc) return rc;
+	const size_t ns = (size_t)s->width * s->height * 4;
+	DevBuf<int> dIds;
+	DevBuf<float> dTab;
+	HIPCHK(dIds.alloc(ns));
+	hipError_t e = hipMemsetAsync(dIds.p, 0xFF, ns * sizeof(int), s->stream);
+	if (e == hipSuccess && t_alpha_beta) {
+		e = dTab.alloc(ns * 3);
+		if (e == hipSuccess) e = hipMemsetAsync(dTab.p, 0, ns * 3 * sizeof(float), s->stream);
+	}
+	if (e != hipSuccess) {
+		dIds.release();
+		dTab.release();
+		return fail(RTX_ERR_DEVICE, hipGetErrorString(e));
+	}
+	rc = render_batches(s, 0, 2, mode, nullptr, dIds.p, t_alpha_beta ? dTab.p : nullptr);
+	if (rc == RTX_OK) {
+		e = hipMemcpy(tri_ids, dIds.p, ns * sizeof(int), hipMemcpyDeviceToHost);
+		if (e == hipSuccess && t_alpha_beta) e = hipMemcpy(t_alpha_beta, dTab.p, ns * 3 * sizeof(float), hipMemcpyDeviceToHost);
+		if (e != hipSuccess) rc = fail(RTX_ERR_DEVICE, hipGetErrorString(e));
+	}
+	dIds.release();
+	dTab.release();
+	if (rc) return rc;
+	s->stats.rays = s->stats.rays_per_level[0];
+	return finish_stats(s);
+}
+
+RTX_API int rtx_trace_rays(rtx_scene* s, int mode, uint32_t n, const float* origins, const float* directions,
+						   int32_t* tri_ids, float* t_alpha_beta) {
+	if (!s || !origins || !directions || !tri_ids) return fail(RTX_ERR_ARG, "null argument");
+	if (mode != 0 && mode != 1) return fail(RTX_ERR_ARG, "mode must be 0 or 1");
+	if (n > (1u << 28)) return fail(RTX_ERR_ARG, "too many rays in one call");
+	int rc = ensure_ready(s, false);
+	if (rc) return rc;
+	rc = begin_call(s);
+	if (rc) return rc;
+	if (n == 0) return RTX_OK;
+	std::vector<float4> ho(n), hd(n);
+	for (uint32_t i = 0; i < n; ++i) {
+		ho[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 0.0f);
+		hd[i] = make_float4(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2], 0.0f);
+	}
+	DevBuf<float4> dO, dD, dH;
+	DevBuf<int> dIds;
+	DevBuf<float> dTab;
+	hipError_t e = dO.alloc(n);
+	if (e == hipSuccess) e = dD.alloc(n);
+	if (e == hipSuccess) e = dH.alloc(n);
+	if (e == hipSuccess) e = dIds.alloc(n);
+	if (e == hipSuccess) e = dTab.alloc((size_t)n * 3);
+	if (e == hipSuccess) e = hipMemcpy(dO.p, ho.data(), (size_t)n * 16, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(dD.p, hd.data(), (size_t)n * 16, hipMemcpyHostToDevice);
+	if (e == hipSuccess) {
+		const DevScene d = make_dev_scene(s);
+		rc = launch_trace(s, d, false, mode == 1, dO.p, dD.p, dH.p, (int)n);
+		if (rc == RTX_OK) {
+			hipLaunchKernelGGL(k_export_hits_linear, dim3((n + 255) / 256), dim3(256), 0, s->stream, d, (int)n, dH.p, dIds.p, dTab.p);
+			e = hipGetLastError();
+			if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+			if (e == hipSuccess) e = hipMemcpy(tri_ids, dIds.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+			if (e == hipSuccess && t_alpha_beta) e = hipMemcpy(t_alpha_beta, dTab.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost);
+		}
+	}
+	dO.release(); dD.release(); dH.release(); dIds.release(); dTab.release();
+	if (e != hipSuccess) return fail(RTX_ERR_DEVICE, hipGetErrorString(e));
+	if (rc) return rc;
+	rc = harvest_events(s);
+	if (rc) return rc;
+	s->stats.rays = n;
+	s->stats.rays_per_level[0] = n;
+	return finish_stats(s);
+}
+
+RTX_API int rtx_sample_radiance(rtx_scene* s, uint32_t frame, float* host_out) {
+	if (!s || !host_out) return fail(RTX_ERR_ARG, "null argument");
+	int rc = ensure_ready(s, true);
+	if (rc) return rc;
+	rc = begin_call(s);
+	if (rc) return rc;
+	const size_t ns = (size_t)s->width * s->height * 4;
+	DevBuf<float4> dOut;
+	HIPCHK(dOut.alloc(ns));
+	hipError_t e = hipMemcpy(dOut.p, host_out, ns * sizeof(float4), hipMemcpyHostToDevice);
+	if (e != hipSuccess) {
+		dOut.release();
+		return fail(RTX_ERR_DEVICE, hipGetErrorString(e));
+	}
+	rc = render_batches(s, frame, 1, 0, dOut.p, nullptr, nullptr);
+	if (rc == RTX_OK) {
+		e = hipMemcpy(host_out, dOut.p, ns * sizeof(float4), hipMemcpyDeviceToHost);
+		if (e != hipSuccess) rc = fail(RTX_ERR_DEVICE, hipGetErrorString(e));
+	}
+	dOut.release();
+	if (rc) return rc;
+	return finish_stats(s);
+}
+
+RTX_API int rtx_scene_set_instrumented(rtx_scene* s, int enabled) {
+	if (!s) return fail(RTX_ERR_ARG, "scene is null");
+	s->instrumented = enabled != 0;
+	return RTX_OK;
+}
+
+RTX_API int rtx_get_stats(rtx_scene* s, rtx_stats* out) {
+	if (!s || !out) return fail(RTX_ERR_ARG, "null argument");
+	*out = s->stats;
+	return RTX_OK;
+}
