@@ -54,6 +54,7 @@ typedef struct rtx_stats {
 	double total_ms;          /* HIP-event time of the whole call on the scene's stream */
 	uint32_t trace_launches;
 	uint32_t chunks;          /* number of pixel batches the frame(s) were split into */
+	double trace_ms_per_level[16];
 } rtx_stats;
 
 /* ------------------------------------------------------------------ device side (librtx_hip.so) */

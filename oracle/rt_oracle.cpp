@@ -35,6 +35,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <random>
 #include <thread>
 #include <tuple>
@@ -147,6 +148,7 @@ struct Scene {
 	float cosT[512], sinT[512];
 	std::atomic<uint64_t> rayCount{0};
 	std::atomic<uint64_t> tirCount{0};
+	float worst[8] = {0};  // candidates, depth, origin xyz, direction xyz of the worst ray of the last render call
 
 	Scene() {
 		// src/Triangle.cpp:6-21
@@ -632,6 +634,10 @@ struct Ctx {
 	std::vector<int> scratch;
 	uint64_t rays = 0;
 	uint64_t tir = 0;
+	// diagnostics: the ray with the longest candidate list seen by this context
+	size_t worstCandidates = 0;
+	Ray worstRay{};
+	int worstDepth = 0;
 };
 
 // RayTracer::color, src/RayTracer.cpp:136-226.
@@ -639,6 +645,11 @@ V4 color(Ctx& cx, int depth, const Ray& r, uint32_t key) {
 	const Scene& s = *cx.s;
 	cx.rays++;
 	Closest c = closest_hit(s, r, cx.scratch);
+	if (cx.scratch.size() > cx.worstCandidates) {
+		cx.worstCandidates = cx.scratch.size();
+		cx.worstRay = r;
+		cx.worstDepth = depth;
+	}
 	if (c.index == -1) {
 		if (s.hasSky) return sample_sky(s, r);
 		return s.bg;
@@ -992,7 +1003,16 @@ ORC_API double orc_render_rows(void* h, int frame, int row0, int row1, float* ac
 		}
 		rays += cx.rays;
 		tirs += cx.tir;
+		static std::mutex mu;
+		std::lock_guard<std::mutex> lk(mu);
+		if ((float)cx.worstCandidates > s.worst[0]) {
+			s.worst[0] = (float)cx.worstCandidates;
+			s.worst[1] = (float)cx.worstDepth;
+			s.worst[2] = cx.worstRay.o.x; s.worst[3] = cx.worstRay.o.y; s.worst[4] = cx.worstRay.o.z;
+			s.worst[5] = cx.worstRay.d.x; s.worst[6] = cx.worstRay.d.y; s.worst[7] = cx.worstRay.d.z;
+		}
 	};
+	s.worst[0] = 0.0f;
 	auto t0 = std::chrono::steady_clock::now();
 	if (nthreads < 1) nthreads = 1;
 	std::vector<std::thread> pool;
@@ -1003,6 +1023,10 @@ ORC_API double orc_render_rows(void* h, int frame, int row0, int row1, float* ac
 	s.tirCount += tirs.load();
 	return std::chrono::duration<double>(t1 - t0).count();
 }
+
+// Diagnostics: candidates, depth, origin, direction of the ray with the longest BVH::hit list in
+// the last orc_render_rows call.
+ORC_API void orc_worst_ray(void* h, float* out8) { std::memcpy(out8, ((Scene*)h)->worst, 32); }
 
 ORC_API uint64_t orc_ray_count(void* h) { return ((Scene*)h)->rayCount.load(); }
 ORC_API uint64_t orc_tir_count(void* h) { return ((Scene*)h)->tirCount.load(); }

@@ -29,11 +29,13 @@ class RtxError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [("rays", _u64), ("rays_per_level", _u64 * 16), ("node_tests", _u64), ("tri_tests", _u64),
                 ("shaded_hits", _u64), ("texture_fetches", _u64), ("trace_ms", C.c_double), ("shade_ms", C.c_double),
-                ("total_ms", C.c_double), ("trace_launches", _u32), ("chunks", _u32)]
+                ("total_ms", C.c_double), ("trace_launches", _u32), ("chunks", _u32),
+                ("trace_ms_per_level", C.c_double * 16)]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "rays_per_level"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if not k.endswith("_per_level")}
         d["rays_per_level"] = [int(x) for x in self.rays_per_level]
+        d["trace_ms_per_level"] = [float(x) for x in self.trace_ms_per_level]
         return d
 
 

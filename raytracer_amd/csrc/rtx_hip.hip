@@ -360,6 +360,17 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 			bool found = false;
 			int sp = 0;
 			int cur = 0;
+			// Rays no triangle can accept are answered without traversal.  A zero direction (the
+			// reference produces one when a diffuse offset cancels the normal, src/Triangle.cpp:115)
+			// makes n.d = +-0, so t is +-inf or NaN and the hit point NaN; a non-finite direction or
+			// a NaN origin makes t NaN or zero.  Triangle::hit rejects all of these
+			// (src/Triangle.cpp:28-29,84), yet BVH::hit would hand it a large part of the tree.
+			if (!EXHAUSTIVE) {
+				const bool zero = (dx == 0.0f) & (dy == 0.0f) & (dz == 0.0f);
+				const bool finite = (fabsf(dx) <= FLT_MAX) & (fabsf(dy) <= FLT_MAX) & (fabsf(dz) <= FLT_MAX) &
+									(r.ox == r.ox) & (r.oy == r.oy) & (r.oz == r.oz);
+				if (zero | !finite) cur = -1;
+			}
 			while (cur >= 0) {
 				const float4* P = sc.pairs + (size_t)cur * 4;
 				float4 lmin = P[0], lmax = P[1], rmin = P[2], rmax = P[3];
@@ -811,7 +822,8 @@ struct DevBuf {
 
 struct EventPair {
 	hipEvent_t a, b;
-	int kind;  // 0 trace, 1 other
+	int kind;   // 0 trace, 1 shade/gather/accumulate, 2 whole call
+	int level;  // path level of a trace launch
 };
 
 }  // namespace
@@ -998,11 +1010,12 @@ struct EventScope {
 	size_t idx;
 };
 
-int begin_event(rtx_scene* s, int kind, size_t& idx) {
+int begin_event(rtx_scene* s, int kind, size_t& idx, int level = 0) {
 	EventPair e;
 	HIPCHK(hipEventCreate(&e.a));
 	HIPCHK(hipEventCreate(&e.b));
 	e.kind = kind;
+	e.level = level;
 	s->events.push_back(e);
 	idx = s->events.size() - 1;
 	HIPCHK(hipEventRecord(e.a, s->stream));
@@ -1019,6 +1032,7 @@ int harvest_events(rtx_scene* s) {
 		HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
 		if (e.kind == 0) {
 			s->stats.trace_ms += ms;
+			s->stats.trace_ms_per_level[e.level & 15] += ms;
 			s->stats.trace_launches++;
 		}
 		else if (e.kind == 1)
@@ -1052,10 +1066,10 @@ int launch_trace_t(rtx_scene* s, const DevScene& d, const float4* ro, const floa
 }
 
 int launch_trace(rtx_scene* s, const DevScene& d, bool anyhit, bool exhaustive, const float4* ro, const float4* rd,
-				 float4* hits, int n) {
+				 float4* hits, int n, int level = 0) {
 	if (n <= 0) return RTX_OK;
 	size_t ev;
-	int rc = begin_event(s, 0, ev);
+	int rc = begin_event(s, 0, ev, level);
 	if (rc) return rc;
 	if (exhaustive)
 		rc = launch_trace_t<false, true>(s, d, ro, rd, hits, n);
@@ -1174,7 +1188,7 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 			C[lv] = (float4*)bump.take((size_t)n * 16);
 			if (!A[lv] || !B[lv] || !C[lv]) return fail(RTX_ERR_MEMORY, "work arena exhausted (internal sizing error)");
 			const int cur = lv & 1, nxt = cur ^ 1;
-			rc = launch_trace(s, d, lv == s->maxDepth, false, rayO[cur], rayD[cur], hit[cur], n);
+			rc = launch_trace(s, d, lv == s->maxDepth, false, rayO[cur], rayD[cur], hit[cur], n, lv);
 			if (rc) return rc;
 			unsigned* cnt = s->dCounts.p + (size_t)(lv + 1) * CNT_STRIDE;
 			const unsigned nextCap = (unsigned)std::min<size_t>((size_t)n * (size_t)bmax, widestCap);

@@ -306,7 +306,7 @@ def atrium_scene(width=1920, height=1080, max_depth=4, n_diff=1, n_spec=1, detai
     sky visible through the open roof. About 262k triangles at detail 1."""
     rng = np.random.default_rng(seed)
     sb = SceneBuilder()
-    sb.set_skybox(1.0, sky_faces(tex_size))
+    sb.set_skybox(2.5, sky_faces(tex_size))
     t_floor = sb.add_texture(checker_texture(tex_size, seed, cells=16))
     t_wall = sb.add_texture(noise_texture(tex_size, seed + 1))
     t_col = sb.add_texture(noise_texture(tex_size, seed + 2, base=(200, 190, 170), amp=35))
@@ -316,7 +316,7 @@ def atrium_scene(width=1920, height=1080, max_depth=4, n_diff=1, n_spec=1, detai
     L, Wd, H = 120.0, 50.0, 60.0   # x extent, z extent, height
     bump = lambda s, t: 0.15 * np.sin(40 * s) * np.sin(40 * t)
     # floor and the two storey floors
-    sb.grid((-L / 2, 0, -Wd / 2), (0, 0, Wd), (L, 0, 0), d(100), d(160), Material((0.9, 0.9, 0.9), rough=0.25, tex=t_floor), disp=bump)
+    sb.grid((-L / 2, 0, -Wd / 2), (0, 0, Wd), (L, 0, 0), d(90), d(150), Material((0.9, 0.9, 0.9), rough=0.25, tex=t_floor), disp=bump)
     # long walls (facing inward) and end walls
     sb.grid((-L / 2, 0, -Wd / 2), (L, 0, 0), (0, H, 0), d(120), d(60), Material((0.85, 0.8, 0.7), rough=0.9, tex=t_wall), disp=bump)
     sb.grid((L / 2, 0, Wd / 2), (-L, 0, 0), (0, H, 0), d(120), d(60), Material((0.85, 0.8, 0.7), rough=0.9, tex=t_wall), disp=bump)
@@ -329,11 +329,11 @@ def atrium_scene(width=1920, height=1080, max_depth=4, n_diff=1, n_spec=1, detai
         for row, z in enumerate((-Wd / 2 + 10, Wd / 2 - 10)):
             xs = np.linspace(-L / 2 + 10, L / 2 - 10, ncol)
             for k, x in enumerate(xs):
-                sb.cylinder((x, y0, z), 1.8, 20.0, d(48), d(40), Material((0.9, 0.88, 0.8), rough=0.7, tex=t_col), flute=0.06)
+                sb.cylinder((x, y0, z), 1.8, 20.0, d(32), d(32), Material((0.9, 0.88, 0.8), rough=0.7, tex=t_col), flute=0.06)
                 sb.box((x - 2.6, y0 + 20.0, z - 2.6), (x + 2.6, y0 + 22.0, z + 2.6), Material((0.85, 0.85, 0.8), rough=0.8), n=d(3))
                 if k + 1 < ncol:
                     xm = 0.5 * (x + xs[k + 1])
-                    sb.arch((xm, y0 + 20.0, z), 0, 0.5 * (xs[k + 1] - x) - 1.0, 1.2, d(40), d(16), Material((0.88, 0.85, 0.8), rough=0.8, tex=t_col))
+                    sb.arch((xm, y0 + 20.0, z), 0, 0.5 * (xs[k + 1] - x) - 1.0, 1.2, d(36), d(16), Material((0.88, 0.85, 0.8), rough=0.8, tex=t_col))
             # gallery slab behind each row
             zs = z - 10 if z < 0 else z
             sb.box((-L / 2, y0 + 24.0, zs), (L / 2, y0 + 26.0, zs + 10), Material((0.8, 0.8, 0.8), rough=0.9), n=d(10))
@@ -342,15 +342,15 @@ def atrium_scene(width=1920, height=1080, max_depth=4, n_diff=1, n_spec=1, detai
         x = -45.0 + 18.0 * k
         phase = rng.uniform(0, 6.28)
         wave = lambda s, t, phase=phase: 1.6 * np.sin(6.0 * s + phase) * (0.3 + t) + 0.5 * np.sin(19 * t + phase)
-        sb.grid((x, 50.0, -6.0), (0, -34.0, 0), (0, 0, 12.0), d(90), d(36),
+        sb.grid((x, 50.0, -6.0), (0, -34.0, 0), (0, 0, 12.0), d(80), d(30),
                 Material((0.9, 0.9, 0.9), rough=1.0, tex=t_cloth[k % 3]), disp=wave)
-        sb.grid((x, 50.0, 6.0), (0, -34.0, 0), (0, 0, -12.0), d(90), d(36),
+        sb.grid((x, 50.0, 6.0), (0, -34.0, 0), (0, 0, -12.0), d(80), d(30),
                 Material((0.9, 0.9, 0.9), rough=1.0, tex=t_cloth[k % 3]), disp=lambda s, t, w=wave: -w(s, 1 - t))
     # feature objects
     sb.sphere((-20, 7, 0), 7.0, d(60), d(80), Material((0.95, 0.85, 0.6), metal=True, rough=0.05))
     sb.sphere((18, 6, 4), 6.0, d(60), d(80), Material((1, 1, 1), transp=True, rough=0.01, ior=1.5))
     # emissive quad under the upper gallery
-    sb.grid((-10, 49.0, -8), (20, 0, 0), (0, 0, 16), 1, 1, Material((12.0, 11.0, 9.5), emit=True))
+    sb.grid((-25, 49.5, -8), (50, 0, 0), (0, 0, 16), 1, 1, Material((14.0, 13.0, 11.0), emit=True))
     tris = sb.triangles()
     return Scene("atrium", tris, sb.textures, sb.sky, eye=(-52.0, 14.0, 3.0), at=(30.0, 16.0, -2.0), focal=22.0,
                  width=width, height=height, max_depth=max_depth, n_diff=n_diff, n_spec=n_spec,
