@@ -1,0 +1,223 @@
+"""Benchmark of the render hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step is one frame (one iteration of the loop at /root/reference/src/RayTracer.cpp:234: four
+samples per pixel through the whole bounce loop, accumulated) of the Sponza-class procedural atrium
+(~263k triangles, textures, cube-map sky) at 1920x1080, max_recursion_depth 4, one diffuse and one
+specular ray per hit -- BASELINE config 3.  The scene, textures and BVH are resident on the GPU before
+the timed region; with N > 1 the image tiles are interleaved over the ranks (fixed total work:
+strong scaling) and every step ends with the RCCL gather of the tile accumulators to rank 0.
+
+Prints one JSON line on rank 0.  `value` is Mrays/s over all ranks: color()-equivalent ray
+queries (primary, secondary, last-depth occlusion) divided by the wall time of the K steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def cpu_baseline(sc, nodes, seconds_target=15.0):
+    """Times the CPU path on this host's cores over a bounded band of rows of the same frame.
+    kind "reference": the reference's own compiled objects (oracle/_ref/libref.so) driven row-parallel;
+    kind "port": the CPU restatement (oracle/liboracle.so).  Never part of the measured GPU path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import binding
+    from util import load_into
+    cores = max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))))
+    port = binding.Oracle()
+    load_into(port, sc, build=False)
+    port.set_nodes(nodes)
+    mid = sc.height // 2
+    use_ref = binding.have_ref()
+    obj = port
+    if use_ref:
+        obj = binding.Reference()
+        load_into(obj, sc, build=True)
+
+    def timed(o, rows):
+        r0 = max(0, mid - rows // 2)
+        acc = np.zeros((sc.height, sc.width, 4), np.float32)
+        return o.render_rows(1, acc, row0=r0, row1=r0 + rows, nthreads=cores), r0
+
+    probe_rows = max(1, cores // 4)
+    t_probe, _ = timed(obj, probe_rows)
+    rows = int(min(sc.height, max(cores // 2, probe_rows * seconds_target / max(t_probe, 1e-3))))
+    port.reset_counts()
+    t, r0 = timed(obj, rows)
+    if use_ref:
+        # the reference cannot count its own color() calls; the restatement renders the same rows
+        # (same scene, same sampling distributions) and its exact count is used
+        timed(port, rows)
+    rays = port.ray_count()
+    samples = rows * sc.width * 4
+    return {
+        "value": round(rays / t / 1e6, 4), "unit": "Mrays/s", "cores": cores,
+        "kind": "reference" if use_ref else "port",
+        "sample": "rows %d..%d of frame 1 of the same 1080p workload (%d samples, %d rays%s), %.1f s on %d threads" % (
+            r0, r0 + rows - 1, samples, rays,
+            "; rays counted by the CPU restatement on the same rows" if use_ref else "", t, cores),
+        "samples_per_s": round(samples / t, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--balance", choices=["static", "dynamic"], default="static")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-instrument", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import api, scenes
+    from raytracer_amd.dist import TileSharder, default_store
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d (launch N>1 through torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    sc = scenes.atrium_scene(width=args.width, height=args.height, max_depth=args.depth)
+    nodes = api.build_bvh(sc.tris)
+    rt = api.RayTracer(local)
+    rt.set_stream(torch.cuda.current_stream().cuda_stream)
+    rt.load_scene(sc, nodes)
+    sharder = TileSharder(sc.width, sc.height, rank, world)
+    accum = torch.zeros((sc.height, sc.width, 4), dtype=torch.float32, device=dev)
+    frame_buf = torch.zeros_like(accum) if args.balance == "dynamic" else None
+    rt.set_accum_device((frame_buf if frame_buf is not None else accum).data_ptr())
+    if args.balance == "static":
+        rt.set_tiles(*sharder.static_share())
+    store = default_store() if (world > 1 and args.balance == "dynamic") else None
+    batch = max(1, sharder.n_tiles // (world * 8))
+
+    counters = {"rays": 0, "trace_ms": 0.0, "shade_ms": 0.0, "launches": 0, "node_tests": 0, "tri_tests": 0,
+                "shaded": 0, "fetches": 0}
+
+    def take_stats():
+        st = rt.stats()
+        counters["rays"] += st["rays"]
+        counters["trace_ms"] += st["trace_ms"]
+        counters["shade_ms"] += st["shade_ms"]
+        counters["launches"] += st["trace_launches"]
+        counters["shaded"] += st["shaded_hits"]
+        counters["fetches"] += st["texture_fetches"]
+
+    def step(frame):
+        if args.balance == "static":
+            rt.render(frame, 1)
+            take_stats()
+            sharder.gather_static(accum)
+        else:
+            frame_buf.zero_()
+            torch.cuda.current_stream().synchronize()
+            if store is None:
+                rt.set_tiles(0, 1, -1)
+                rt.render(frame, 1)
+                take_stats()
+            else:
+                for first, count in sharder.dynamic_batches(store, frame, batch):
+                    rt.set_tiles(first, 1, count)
+                    rt.render(frame, 1)
+                    take_stats()
+            sharder.reduce_frame(frame_buf, accum)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    frame = 1
+    for _ in range(args.warmup):
+        step(frame)
+        frame += 1
+    for k in counters:
+        counters[k] = 0
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(frame)
+        frame += 1
+    sync()
+    dt = time.perf_counter() - t0
+
+    tot = torch.tensor([dt, float(counters["rays"]), counters["trace_ms"], counters["shade_ms"]], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tot.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+    rays_total = float(tot[1])
+    trace_ms_sum = float(tot[2])
+    shade_ms_sum = float(tot[3])
+
+    # node/triangle test counts of this rank's share, from one instrumented frame outside the timed region
+    # (frame `frame - 1` again: identical rays); they feed the algorithmic-bytes figure of the trace kernel.
+    n_node = n_tri = None
+    if not args.no_instrument and args.balance == "static":
+        rt.set_instrumented(True)
+        rt.render(frame - 1, 1)
+        st = rt.stats()
+        rt.set_instrumented(False)
+        n_node = st["node_tests"] / max(st["rays"], 1)
+        n_tri = st["tri_tests"] / max(st["rays"], 1)
+
+    if rank == 0:
+        samples = sc.width * sc.height * 4 * args.steps
+        out = {
+            "metric": "Mrays/s (incl. secondary) at 1080p", "value": round(rays_total / dt / 1e6, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "atrium (Sponza-class, %d triangles, %d textures + cube-map sky) %dx%d, 4 spp per step, "
+                                   "max_recursion_depth %d, diffuse 1, specular 1" % (len(sc.tris), len(sc.textures), sc.width, sc.height, sc.max_depth),
+                       "sharding": "tile-interleave x%d, %s" % (world, "gather to rank 0 per step" if args.balance == "static" else "dynamic batches + reduce per step")},
+            "samples_per_s": round(samples / dt, 1),
+            "rays_per_step": round(rays_total / args.steps),
+            "gpu_kernel_ms_per_step": {"trace": round(trace_ms_sum / args.steps / world, 3), "shade_gather_accumulate": round(shade_ms_sum / args.steps / world, 3)},
+        }
+        if n_node is not None:
+            # algorithmic bytes the traversal kernel must move per ray: 32 B per box test (half of a 64-B
+            # pair record), 64 B per triangle test, 32 B ray in, 16 B hit out
+            bytes_per_ray = 32.0 * n_node + 64.0 * n_tri + 48.0
+            achieved = bytes_per_ray * rays_total / (trace_ms_sum / world * 1e-3) / 1e9 if trace_ms_sum > 0 else 0.0
+            out["roofline"] = {"bound": "hbm", "kernel": "k_trace", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                               "box_tests_per_ray": round(n_node, 2), "triangle_tests_per_ray": round(n_tri, 3),
+                               "bytes_per_ray": round(bytes_per_ray, 1),
+                               "avg_launch_ms": round(trace_ms_sum / max(counters["launches"] * world, 1), 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, nodes)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,8 +82,6 @@ def _load(path, table):
         raise RtxError(-3, "%s is missing: run `python -m raytracer_amd.build` (there is no CPU fallback)" % path)
     lib = C.CDLL(path)
     for name, (res, args) in table.items():
-        if name == "rtxh_run_config" and not hasattr(lib, name):
-            continue
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args

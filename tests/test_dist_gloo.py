@@ -1,0 +1,95 @@
+"""The multi-rank exchange (raytracer_amd/dist.py) with world_size 2 on the gloo backend, CPU only.
+Rendering is replaced by a deterministic per-pixel function so that the test exercises exactly the
+sharding logic: static tile interleave + gather, and dynamic batches + sum-reduce."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raytracer_amd.dist import TILE, TileSharder, default_store
+
+W, H = 200, 150   # ragged: 4 x 3 tiles with partial right/bottom tiles
+
+
+def fake_render(frame, tiles, tiles_x):
+    """What a rank would add to its accumulator for `tiles` in `frame`: f(pixel, frame), zero elsewhere."""
+    img = torch.zeros((H, W, 4), dtype=torch.float32)
+    y, x = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    val = (torch.sin(x * 0.37 + y * 0.11 + frame) + 1.5).to(torch.float32)
+    tile_of = (y // TILE) * tiles_x + (x // TILE)
+    mask = torch.zeros_like(tile_of, dtype=torch.bool)
+    for t in tiles:
+        mask |= tile_of == t
+    for c in range(3):
+        img[..., c] = torch.where(mask, val * (c + 1), torch.zeros_like(val))
+    return img
+
+
+def expected(frames):
+    sh = TileSharder(W, H)
+    acc = torch.zeros((H, W, 4), dtype=torch.float32)
+    for f in frames:
+        acc += fake_render(f, range(sh.n_tiles), sh.tiles_x)
+    return acc
+
+
+def worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sh = TileSharder(W, H, rank, world)
+        # static: accumulators live on the owners, gathered once
+        first, stride, _ = sh.static_share()
+        mine = list(range(first, sh.n_tiles, stride))
+        acc = torch.zeros((H, W, 4), dtype=torch.float32)
+        for f in (1, 2, 3):
+            acc += fake_render(f, mine, sh.tiles_x)
+        img = sh.gather_static(acc)
+        # dynamic: tiles pulled from the shared counter, frame buffers reduced
+        store = default_store()
+        total = torch.zeros((H, W, 4), dtype=torch.float32)
+        pulled = 0
+        for f in (1, 2, 3):
+            buf = torch.zeros((H, W, 4), dtype=torch.float32)
+            for start, count in sh.dynamic_batches(store, f, 2):
+                buf += fake_render(f, range(start, start + count), sh.tiles_x)
+                pulled += count
+            dist.barrier()
+            res = sh.reduce_frame(buf, total)
+        cnt = torch.tensor([pulled])
+        dist.all_reduce(cnt)
+        if rank == 0:
+            np.save(out + "_static.npy", img.numpy())
+            np.save(out + "_dynamic.npy", res.numpy())
+            np.save(out + "_pulled.npy", cnt.numpy())
+        else:
+            assert img is None and res is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_static_gather_and_dynamic_reduce(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "img")
+    mp.spawn(worker, args=(2, port, out), nprocs=2, join=True)
+    want = expected((1, 2, 3)).numpy()
+    sh = TileSharder(W, H)
+    assert np.array_equal(np.load(out + "_static.npy").view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(np.load(out + "_dynamic.npy").view(np.uint32), want.view(np.uint32))
+    assert np.load(out + "_pulled.npy")[0] == 3 * sh.n_tiles
+
+
+def test_tile_views_roundtrip():
+    from raytracer_amd.dist import _as_tiles, _from_tiles
+    sh = TileSharder(W, H)
+    img = torch.rand((H, W, 4))
+    back = _from_tiles(_as_tiles(img, sh.tiles_x, sh.tiles_y), sh.tiles_x, sh.tiles_y, W, H)
+    assert torch.equal(img, back)
+    assert sh.n_tiles == 12 and TileSharder(W, H, 1, 2).owned().tolist() == [1, 3, 5, 7, 9, 11]

@@ -1,0 +1,278 @@
+"""Parity of the HIP path (through the C ABI of include/rtx.h) with the CPU restatement and with the
+golden vectors taken from the reference.  Needs an MI355X: run with -m gpu.
+
+Bar: primary-hit triangle ids, t/alpha/beta, per-sample radiance and accumulators are all compared
+bit for bit (integer ids exactly; float32 values by their bit patterns).  At full BASELINE sizes,
+where the CPU restatement would take minutes, the checks are size-independent properties:
+culled traversal == exhaustive traversal, tile shares compose to the whole image, small work arenas
+give the same image as large ones, repeated runs are identical.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding
+from raytracer_amd import api, scenes
+from scene_io import load_fixture, oracle_from_fixture, scene_from_fixture
+from util import assert_bits_equal, bits, load_into
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def libs():
+    from raytracer_amd import build
+    for p in (build.HIP_SO, build.HOST_SO, binding.ORACLE_SO):
+        assert os.path.exists(p), "%s must be built before the GPU tests run (no building on the GPU box)" % p
+    assert api.hip_lib().rtx_device_count() >= 1
+    return api
+
+
+def gpu_scene(sc, cam=None):
+    rt = api.RayTracer(0)
+    rt.load_scene(sc)
+    if cam is not None:
+        rt.set_camera_raw(cam)
+    return rt
+
+
+# ---------------------------------------------------------------- against the golden vectors
+
+@pytest.mark.parametrize("name", ["scene_mixed.npz", "scene_mixed_nosky.npz"])
+def test_primary_hits_match_reference_goldens(libs, name):
+    g = load_fixture(name)
+    sc = scene_from_fixture(g)
+    rt = gpu_scene(sc, sc.cam)
+    for mode in (0, 1):
+        ids, tab = rt.primary_hits(mode)
+        assert np.array_equal(ids, g["hit_ids"]), "mode %d: %d ids differ" % (mode, (ids != g["hit_ids"]).sum())
+        hit = ids >= 0
+        assert_bits_equal(tab[hit], g["hit_tab"][hit], "t/alpha/beta mode %d" % mode)
+    eids, etab = rt.trace_rays(g["edge_o"], g["edge_d"], 0)
+    assert np.array_equal(eids, g["edge_ids"])
+    hit = eids >= 0
+    assert_bits_equal(etab[hit], g["edge_tab"][hit], "edge rays")
+    eids1, _ = rt.trace_rays(g["edge_o"], g["edge_d"], 1)
+    assert np.array_equal(eids1, g["edge_ids"])
+
+
+# ---------------------------------------------------------------- against the CPU restatement
+
+@pytest.mark.parametrize("seed,w,h,depth,nd,ns,sky", [
+    (1, 96, 80, 3, 2, 1, True),
+    (2, 70, 45, 2, 1, 2, False),
+    (3, 33, 129, 4, 1, 1, True),      # ragged: neither a multiple of 4 nor of 64
+    (4, 64, 64, 1, 3, 2, True),       # depth 1: children are pure occlusion queries
+])
+def test_radiance_and_accumulator_bit_exact(libs, seed, w, h, depth, nd, ns, sky):
+    sc = scenes.mixed_scene(seed=seed, width=w, height=h, max_depth=depth, n_diff=nd, n_spec=ns, with_sky=sky)
+    O = load_into(binding.Oracle(), sc)
+    rt = gpu_scene(sc)
+    ids_o, tab_o = O.primary_hits()
+    ids_g, tab_g = rt.primary_hits(0)
+    assert np.array_equal(ids_o, ids_g)
+    hit = ids_o >= 0
+    assert_bits_equal(tab_o[hit], tab_g[hit], "t/alpha/beta")
+    rad_o = O.sample_radiance(2, 0, 0, w, h)
+    rad_g = rt.sample_radiance(2)
+    assert_bits_equal(rad_o[..., :3], rad_g[..., :3], "per-sample radiance")
+    assert (rad_o[..., :3] > 0).mean() > 0.2
+    acc_o = np.zeros((h, w, 4), np.float32)
+    O.reset_counts()
+    for f in (1, 2, 3):
+        O.render_rows(f, acc_o, nthreads=8)
+    rt.reset()
+    rt.render(1, 3)
+    assert_bits_equal(acc_o[..., :3], rt.accum()[..., :3], "accumulator after 3 frames")
+    assert rt.stats()["rays"] == O.ray_count()
+    # tone map on the host side of the product equals the restatement's
+    assert np.array_equal(api.tonemap(rt.accum(), 3), O.tonemap(acc_o, 3))
+
+
+def test_secondary_like_rays_and_degenerate_rays(libs):
+    sc = scenes.mixed_scene(seed=4, width=16, height=16, detail=0.8)
+    O = load_into(binding.Oracle(), sc)
+    rt = gpu_scene(sc)
+    rng = np.random.default_rng(11)
+    n = 20000
+    o = rng.uniform(-35, 35, (n, 3)).astype(np.float32)
+    o[:, 1] = np.abs(o[:, 1])
+    d = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    d[:300, 0] = 0
+    d[300:600, 1] = 0
+    d[600:900, [0, 1]] = 0
+    d[900:910] = 0                      # zero directions: must miss
+    d[910:920, 2] = np.nan              # NaN directions: must miss
+    d[920:930, 0] = np.inf
+    o[930:940, 1] = np.nan
+    o[1000:2000] = np.round(o[1000:2000])
+    o[2000:2200, 1] = 0.0               # origins exactly on the floor plane
+    d[2200:2400] *= np.float32(1e-7)
+    d[2400:2600] *= np.float32(1e7)
+    ids_o, tab_o = O.closest_hits(o, d)
+    for mode in (0, 1):
+        ids_g, tab_g = rt.trace_rays(o, d, mode)
+        assert np.array_equal(ids_o, ids_g), "mode %d: %d differ" % (mode, (ids_o != ids_g).sum())
+        hit = ids_o >= 0
+        assert_bits_equal(tab_o[hit], tab_g[hit], "t/alpha/beta mode %d" % mode)
+    assert (ids_o[900:940] == -1).all()
+    assert 0.3 < (ids_o >= 0).mean() < 0.99
+
+
+def test_ties_resolve_in_reference_candidate_order(libs):
+    """Stacks of exactly coincident triangles: every ray sees equal t from several candidates; the
+    winner must be the first in the reference's depth-first candidate order."""
+    base = scenes.mixed_scene(seed=8, width=48, height=48, detail=0.5, with_sky=False).tris
+    rng = np.random.default_rng(5)
+    pick = rng.choice(len(base), 60, replace=False)
+    dup = np.concatenate([base[pick]] * 3)
+    dup["color"][:, 0] = np.linspace(0, 1, len(dup))
+    tris = np.concatenate([base, dup])[rng.permutation(len(base) + len(dup))]
+    sc = scenes.mixed_scene(seed=8, width=48, height=48, detail=0.5, with_sky=False)
+    sc.tris = tris
+    O = load_into(binding.Oracle(), sc)
+    rt = gpu_scene(sc)
+    ids_o, _ = O.primary_hits()
+    for mode in (0, 1):
+        ids_g, _ = rt.primary_hits(mode)
+        assert np.array_equal(ids_o, ids_g)
+
+
+def test_empty_and_single_triangle_scenes(libs):
+    sc = scenes.mixed_scene(seed=1, width=20, height=12, with_sky=True)
+    for n in (0, 1, 2):
+        sc.tris = scenes.mixed_scene(seed=1).tris[:n]
+        O = load_into(binding.Oracle(), sc)
+        rt = gpu_scene(sc)
+        ids_o, _ = O.primary_hits()
+        ids_g, _ = rt.primary_hits(0)
+        assert np.array_equal(ids_o, ids_g)
+        acc_o = np.zeros((sc.height, sc.width, 4), np.float32)
+        O.render_rows(1, acc_o, nthreads=2)
+        rt.reset()
+        rt.render(1, 1)
+        assert_bits_equal(acc_o[..., :3], rt.accum()[..., :3], "accumulator n=%d" % n)
+
+
+# ---------------------------------------------------------------- properties at BASELINE sizes
+
+def test_bunny_class_1080p_culled_equals_exhaustive(libs):
+    """BASELINE config 2 (bunny-class mesh, ~69.5k triangles, 1080p, primary rays): the production
+    traversal returns the same triangle for every one of the 8.3M rays as the traversal that
+    visits exactly the reference's candidate set; a 64x36 window is also checked against the CPU."""
+    sc = scenes.bunny_class_scene()
+    rt = gpu_scene(sc)
+    ids0, tab0 = rt.primary_hits(0)
+    s0 = rt.stats()
+    ids1, tab1 = rt.primary_hits(1)
+    assert ids0.size == 1920 * 1080 * 4
+    assert np.array_equal(ids0, ids1)
+    assert_bits_equal(tab0[ids0 >= 0], tab1[ids0 >= 0], "t/alpha/beta")
+    assert 0.2 < (ids0 >= 0).mean() < 0.9
+    O = binding.Oracle()
+    load_into(O, sc, build=False)
+    O.set_nodes(api.build_bvh(sc.tris))
+    x0, y0 = 928, 522
+    ids_o, tab_o = O.primary_hits(x0, y0, x0 + 64, y0 + 36)
+    win = ids0.reshape(1080, 1920, 4)[y0:y0 + 36, x0:x0 + 64].reshape(-1)
+    assert np.array_equal(ids_o, win)
+    assert s0["rays"] == 1920 * 1080 * 4
+
+
+def test_atrium_tiles_arena_and_determinism(libs):
+    """Sponza-class scene at reduced resolution: (a) two tile shares rendered separately compose to
+    the single-share image, (b) a work arena 20x smaller (many pixel batches) gives the same image,
+    (c) a second run is identical, (d) a window of the image equals the CPU restatement."""
+    sc = scenes.atrium_scene(width=320, height=200, max_depth=4)
+    nodes = api.build_bvh(sc.tris)
+    rt = api.RayTracer(0)
+    rt.load_scene(sc, nodes)
+    rt.reset()
+    rt.render(1, 2)
+    full = rt.accum()
+    st = rt.stats()
+    assert st["chunks"] == 2
+    # (c)
+    rt.reset()
+    rt.render(1, 2)
+    assert_bits_equal(full, rt.accum(), "repeat")
+    # (b)
+    rt.set_arena_bytes(int(320 * 200 * 4 * 3000 / 20))
+    rt.reset()
+    rt.render(1, 2)
+    assert rt.stats()["chunks"] > 10
+    assert_bits_equal(full, rt.accum(), "small arena")
+    rt.set_arena_bytes(0)
+    # (a)
+    parts = []
+    for r in range(2):
+        rt.set_tiles(r, 2, -1)
+        rt.reset()
+        rt.render(1, 2)
+        parts.append(rt.accum())
+    rt.set_tiles(0, 1, -1)
+    tiles_x = (sc.width + 63) // 64
+    merged = np.zeros_like(full)
+    for y0 in range(0, sc.height, 64):
+        for x0 in range(0, sc.width, 64):
+            owner = ((y0 // 64) * tiles_x + x0 // 64) % 2
+            merged[y0:y0 + 64, x0:x0 + 64] = parts[owner][y0:y0 + 64, x0:x0 + 64]
+            other = parts[1 - owner][y0:y0 + 64, x0:x0 + 64]
+            assert not other.any(), "a device wrote outside its tiles"
+    assert_bits_equal(full, merged, "tile shares")
+    # (d)
+    O = binding.Oracle()
+    load_into(O, sc, build=False)
+    O.set_nodes(nodes)
+    acc_o = np.zeros((sc.height, sc.width, 4), np.float32)
+    for f in (1, 2):
+        O.render_rows(f, acc_o, row0=96, row1=104, nthreads=8)
+    assert_bits_equal(acc_o[96:104, :, :3], full[96:104, :, :3], "rows 96..103 vs CPU")
+
+
+def test_external_accumulator_and_resume(libs):
+    import torch
+    sc = scenes.mixed_scene(seed=2, width=64, height=40)
+    rt = gpu_scene(sc)
+    rt.reset()
+    rt.render(1, 4)
+    want = rt.accum()
+    ext = torch.zeros((sc.height, sc.width, 4), dtype=torch.float32, device="cuda:0")
+    rt.set_accum_device(ext.data_ptr())
+    rt.render(1, 2)
+    torch.cuda.synchronize()
+    half = ext.cpu().numpy()
+    rt.set_accum_device(None)
+    rt.write_accum(half)      # resume from a saved accumulator
+    rt.render(3, 2)
+    assert_bits_equal(want, rt.accum(), "resume")
+
+
+def test_error_paths(libs):
+    lib = api.hip_lib()
+    h = C.c_void_p()
+    assert lib.rtx_scene_create(C.byref(h), 9999) == -1
+    assert lib.rtx_scene_create(C.byref(h), 0) == 0
+    assert lib.rtx_render_frames(h, 1, 1) == -2 and b"set_params" in lib.rtx_last_error()
+    bg = (C.c_float * 3)(0, 0, 0)
+    assert lib.rtx_scene_set_params(h, 0, 10, 1, 1, 1, bg, 0) == -1
+    assert lib.rtx_scene_set_params(h, 16, 16, 16, 1, 1, bg, 0) == -1
+    assert lib.rtx_scene_set_params(h, 16, 16, 2, 1, 1, bg, 0) == 0
+    tris = scenes.mixed_scene(detail=0.4).tris.copy()
+    nodes = api.build_bvh(tris)
+    assert lib.rtx_scene_set_bvh(h, nodes.ctypes.data, len(nodes)) == -2      # triangles first
+    bad = tris.copy()
+    bad["v"][3, 1, 3] = 1.0
+    assert lib.rtx_scene_set_triangles(h, bad.ctypes.data, len(bad)) == -1    # w lane not zero
+    assert lib.rtx_scene_set_triangles(h, tris.ctypes.data, len(tris)) == 0
+    broken = nodes.copy()
+    broken["left"][0] = len(nodes) + 5
+    assert lib.rtx_scene_set_bvh(h, broken.ctypes.data, len(broken)) == -1
+    broken = nodes.copy()
+    broken["tri"][broken["tri"] >= 0] = 0
+    assert lib.rtx_scene_set_bvh(h, broken.ctypes.data, len(broken)) == -1    # one triangle in every leaf
+    assert lib.rtx_scene_set_bvh(h, nodes.ctypes.data, len(nodes)) == 0
+    assert lib.rtx_render_frames(h, 1, 1) == -2                                  # no camera, no tables
+    lib.rtx_scene_destroy(h)

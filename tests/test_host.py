@@ -1,0 +1,104 @@
+"""Host-side product code (librtx_host.so) against the CPU restatement and the golden vectors, and
+the export tables of both product libraries against include/rtx.h.  No GPU needed."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from raytracer_amd import api, scenes
+from scene_io import load_fixture, nodes_fields, scene_from_fixture
+from util import ROOT, assert_bits_equal
+
+
+def _declared(prefix):
+    text = open(os.path.join(ROOT, "include", "rtx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(%s[a-z_0-9]+)\s*\(" % prefix, text)))
+
+
+def test_every_declared_symbol_is_exported(native_libs):
+    hip = ctypes.CDLL(native_libs.HIP_SO)   # loading initialises nothing on the GPU
+    host = ctypes.CDLL(native_libs.HOST_SO)
+    dev = _declared("rtx_")
+    hst = _declared("rtxh_")
+    assert len(dev) >= 20 and len(hst) >= 6
+    for name in dev:
+        assert hasattr(hip, name), name
+    for name in hst:
+        assert hasattr(host, name), name
+    # and the ctypes tables used by the Python host cover exactly the header
+    assert sorted(api.HIP_SYMBOLS) == dev
+    assert sorted(api.HOST_SYMBOLS) == hst
+
+
+def test_camera_matches_golden(native_libs):
+    g = load_fixture("camera.npz")
+    for i in range(len(g["rot"])):
+        w, h = [int(x) for x in g["size"][i]]
+        cam = api.camera(g["eye"][i], g["at"][i], float(g["focal"][i]), float(g["rot"][i]), w, h)
+        assert_bits_equal(cam, g["cam"][i], "camera %d" % i)
+
+
+@pytest.mark.parametrize("name", ["scene_mixed.npz", "scene_mixed_nosky.npz"])
+def test_bvh_builder_matches_golden(native_libs, name):
+    g = load_fixture(name)
+    sc = scene_from_fixture(g)
+    assert np.array_equal(nodes_fields(api.build_bvh(sc.tris)), g["nodes"])
+
+
+def test_bvh_builder_tiny_and_empty(native_libs):
+    g = load_fixture("bvh_tiny.npz")
+    for i in range(9):
+        tris = np.ascontiguousarray(g["tris%d" % i]).view(scenes.TRI_DTYPE).reshape(-1)
+        assert np.array_equal(nodes_fields(api.build_bvh(tris)), g["nodes%d" % i]), i
+    nodes = api.build_bvh(np.zeros(0, scenes.TRI_DTYPE))
+    assert len(nodes) == 1 and nodes["left"][0] == -1 and nodes["right"][0] == -1 and nodes["tri"][0] == -1
+
+
+def test_bvh_builder_parallel_path_matches_oracle(native_libs, oracle_lib):
+    """Above 16k triangles the builder hands subtrees to worker threads; the tree must not change."""
+    sc = scenes.bunny_class_scene(width=8, height=8, rings=100, segs=101)
+    tris = np.concatenate([sc.tris, sc.tris[:2000]])
+    O = oracle_lib.Oracle()
+    O.set_params(8, 8, 1, 1, 1)
+    O.set_triangles(tris)
+    O.build_bvh()
+    assert len(tris) > 16384
+    assert np.array_equal(nodes_fields(api.build_bvh(tris)), nodes_fields(O.get_nodes()))
+
+
+def test_make_triangle_matches_golden(native_libs):
+    g = load_fixture("add_triangle.npz")
+    for i in range(32):
+        t = api.make_triangle(g["v"][i, 0], g["v"][i, 1], g["v"][i, 2], g["side"][i], (0.1 * i, 0.5, 1.0), i & 1, (i >> 1) & 1,
+                              (i >> 2) & 1, 0.25 * i, 1.0 + 0.01 * i)
+        b = t.view(np.uint8).reshape(-1)[:167]
+        assert np.array_equal(b[:128], g["tris"][i][:128]) and np.array_equal(b[152:], g["tris"][i][152:]), i
+
+
+def test_tables_and_tonemap(native_libs, oracle_lib):
+    O = oracle_lib.Oracle()
+    for a, b in zip(api.tables(), O.tables()):
+        assert_bits_equal(a, b, "table")
+    g = load_fixture("image_mt.npz")
+    acc = np.zeros(g["accum"].shape[:2] + (4,), np.float32)
+    acc[..., :3] = g["accum"]
+    assert np.array_equal(api.tonemap(acc, 1).reshape(g["rgb8"].shape), g["rgb8"])
+    rng = np.random.default_rng(1)
+    acc = rng.uniform(-0.1, 3.0, (500, 4)).astype(np.float32)
+    for frame in (1, 3, 64):
+        assert np.array_equal(api.tonemap(acc, frame), O.tonemap(acc, frame))
+
+
+def test_host_errors(native_libs):
+    with pytest.raises(api.RtxError):
+        api.camera((0, 0, 0), (0, 0, 1), 30.0, 0.0, 0, 10)
+    lib = api.host_lib()
+    rc = lib.rtxh_build_bvh(None, 5, None, 0)
+    assert rc == -1 and b"null" in lib.rtxh_last_error()
+    tris = scenes.mixed_scene(detail=0.4).tris
+    nodes = np.zeros(4, scenes.NODE_DTYPE)
+    rc = lib.rtxh_build_bvh(tris.ctypes.data, len(tris), nodes.ctypes.data, 4)
+    assert rc == -1 and b"too small" in lib.rtxh_last_error()
