@@ -1170,7 +1170,6 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 			hipLaunchKernelGGL(k_export_hits, dim3((b.nSamples + 255) / 256), dim3(256), 0, s->stream, d, b, hit[0], dIds, dTab);
 			HIPCHK(hipGetLastError());
 			HIPCHK(hipStreamSynchronize(s->stream));
-			s->stats.rays_per_level[0] += (uint64_t)b.nSamples;
 			continue;
 		}
 
@@ -1622,7 +1621,15 @@ RTX_API int rtx_primary_hits(rtx_scene* s, int mode, int32_t* tri_ids, float* t_
 	dIds.release();
 	dTab.release();
 	if (rc) return rc;
-	s->stats.rays = s->stats.rays_per_level[0];
+	// primary rays actually traced: pixels of this scene's tiles that lie inside the image
+	uint64_t px = 0;
+	const int tilesX = (s->width + TILE - 1) / TILE;
+	for (int k = 0, n = tile_slots(s); k < n; ++k) {
+		const int tile = s->tileFirst + k * s->tileStride;
+		const int tx = tile % tilesX, ty = tile / tilesX;
+		px += (uint64_t)std::min(TILE, s->width - tx * TILE) * (uint64_t)std::min(TILE, s->height - ty * TILE);
+	}
+	s->stats.rays = s->stats.rays_per_level[0] = px * 4;
 	return finish_stats(s);
 }
 
