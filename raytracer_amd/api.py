@@ -95,6 +95,14 @@ _host = None
 def hip_lib():
     global _hip
     if _hip is None:
+        # A process can hold only one HIP runtime on the GPU.  PyTorch ships its own copy of libamdhip64;
+        # if torch is going to be used in this process (device tensors as accumulators, torch.distributed) it
+        # has to be loaded first so that librtx_hip.so binds to that same copy instead of bringing in the
+        # system one, after which torch would find "no HIP GPUs".
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _hip = _load(_build.HIP_SO, HIP_SYMBOLS)
     return _hip
 

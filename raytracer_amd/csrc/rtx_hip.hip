@@ -37,6 +37,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -329,95 +330,179 @@ __device__ __forceinline__ bool box_test(const RaySlab& r, float4 bmin, float4 b
 // ANYHIT: only "some candidate is accepted" is needed (rays at the last recursion depth,
 // src/RayTracer.cpp:154-171); x = 0 then stands for "hit".
 // EXHAUSTIVE: no culling, i.e. the candidate set of BVH::hit itself.
+//
+// Persistent waves: rays of one queue differ in traversal length by orders of magnitude, so a wave
+// that takes 64 rays and waits for the slowest runs mostly empty.  Here a wave keeps running and, once
+// REFILL or more of its lanes are idle, hands them the next rays of its private chunk of the queue
+// (CHUNK consecutive rays claimed with one atomic on *work, which the host zeroes before the launch).
+// Every wave leaves the loop when the queue is exhausted and its lanes have drained.
+constexpr int TRACE_CHUNK = 256;
+constexpr int TRACE_REFILL = 32;
+
 template <int STACK, bool ANYHIT, bool EXHAUSTIVE, bool STATS>
 __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const float4* __restrict__ rayO,
 														  const float4* __restrict__ rayD, float4* __restrict__ hits,
-														  int n, unsigned long long* __restrict__ stats) {
+														  int n, unsigned long long* __restrict__ stats,
+														  unsigned* __restrict__ work, int refill, int chunk, int triBatch) {
 	__shared__ int stk[STACK][TRACE_THREADS];
+	__shared__ float stkT[STATS ? STACK : 1][TRACE_THREADS];  // diagnostics only: entry bound of pushed nodes
+	unsigned pops = 0, popsBeyond = 0;
 	const int tid = threadIdx.x;
-	const int j = blockIdx.x * TRACE_THREADS + tid;
+	const unsigned lane = (unsigned)tid & 63u;
+	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+
 	unsigned nodeTests = 0, triTests = 0;
-	if (j < n) {
-		float4 O = rayO[j];
-		float4 D = rayD[j];
-		if (D.w != 0.0f) {
-			hits[j] = make_float4(__int_as_float(-2), FLT_MAX, 0.0f, 0.0f);
-		}
-		else {
-			RaySlab r;
-			r.ox = O.x; r.oy = O.y; r.oz = O.z;
-			const float dx = D.x, dy = D.y, dz = D.z;
-			r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
-			r.nx = (__float_as_uint(r.ix) >> 31) != 0;
-			r.ny = (__float_as_uint(r.iy) >> 31) != 0;
-			r.nz = (__float_as_uint(r.iz) >> 31) != 0;
-			// Position-space slack for culling: 2^-14 of the largest coordinate magnitude in play.
-			float scale = fmaxf(fmaxf(sc.sceneAbsMax, fabsf(r.ox)), fmaxf(fabsf(r.oy), fabsf(r.oz)));
-			float eps = scale * 6.103515625e-05f;
-			r.mx = eps * fabsf(r.ix); r.my = eps * fabsf(r.iy); r.mz = eps * fabsf(r.iz);
-			HitState best;
-			best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
-			bool found = false;
-			int sp = 0;
-			int cur = 0;
-			// Rays no triangle can accept are answered without traversal.  A zero direction (the
-			// reference produces one when a diffuse offset cancels the normal, src/Triangle.cpp:115)
-			// makes n.d = +-0, so t is +-inf or NaN and the hit point NaN; a non-finite direction or
-			// a NaN origin makes t NaN or zero.  Triangle::hit rejects all of these
-			// (src/Triangle.cpp:28-29,84), yet BVH::hit would hand it a large part of the tree.
-			if (!EXHAUSTIVE) {
-				const bool zero = (dx == 0.0f) & (dy == 0.0f) & (dz == 0.0f);
-				const bool finite = (fabsf(dx) <= FLT_MAX) & (fabsf(dy) <= FLT_MAX) & (fabsf(dz) <= FLT_MAX) &
-									(r.ox == r.ox) & (r.oy == r.oy) & (r.oz == r.oz);
-				if (zero | !finite) cur = -1;
+	// wave-uniform: the chunk this wave is handing out
+	int cnext = 0, cend = 0;
+	bool more = true;
+	// per lane: the ray in flight (cur < 0: none)
+	int j = -1, cur = -1, sp = 0;
+	RaySlab r;
+	r.ox = r.oy = r.oz = r.ix = r.iy = r.iz = r.mx = r.my = r.mz = 0.0f;
+	r.nx = r.ny = r.nz = false;
+	float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+	HitState best;
+	best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
+	bool found = false;
+
+	// Leaf children are not intersected where they are found: a lane parks them (at most two, the two
+	// children of one pair) and waits.  Once triBatch lanes are parked, or nobody can traverse any more,
+	// the wave runs the triangle code once for all of them.  The address path issues one vector-memory
+	// instruction per ~22 clocks per CU however few lanes it serves, so four loads for one or two lanes
+	// per step would cost as much as the box loads of the whole wave.
+	bool busy = false;
+	int pend0 = -1, pend1 = -1;
+	for (;;) {
+		const unsigned long long idle = __ballot(!busy);
+		const int nidle = __popcll(idle);
+		if (more && nidle >= refill) {
+			if (cnext >= cend) {
+				unsigned base = 0;
+				if (lane == 0) base = atomicAdd(work, (unsigned)chunk);
+				base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+				if (base >= (unsigned)n) {
+					more = false;
+					cnext = cend = 0;
+				}
+				else {
+					cnext = (int)base;
+					cend = min((int)base + chunk, n);
+				}
 			}
-			while (cur >= 0) {
-				const float4* P = sc.pairs + (size_t)cur * 4;
-				float4 lmin = P[0], lmax = P[1], rmin = P[2], rmax = P[3];
-				int codeL = __float_as_int(lmin.w);
-				int codeR = __float_as_int(rmin.w);
-				float teL, txL, teR, txR;
-				bool hitL = box_test(r, lmin, lmax, teL, txL) && codeL != 0;
-				bool hitR = box_test(r, rmin, rmax, teR, txR) && codeR != 0;
-				if (STATS) nodeTests += (codeL != 0) + (codeR != 0);
-				if (!EXHAUSTIVE) {
-					hitL = hitL && !(txL < 0.001f) && !(teL > best.t);
-					hitR = hitR && !(txR < 0.001f) && !(teR > best.t);
-				}
-				if (hitL && codeL < 0) {
-					if (STATS) triTests++;
-					found |= tri_test(sc.triHit, ~codeL, r.ox, r.oy, r.oz, dx, dy, dz, best);
-				}
-				if (hitR && codeR < 0 && !(ANYHIT && found)) {
-					if (STATS) triTests++;
-					found |= tri_test(sc.triHit, ~codeR, r.ox, r.oy, r.oz, dx, dy, dz, best);
-				}
-				if (ANYHIT && found) break;
-				bool intL = hitL && codeL > 0;
-				bool intR = hitR && codeR > 0;
-				if (!EXHAUSTIVE) {
-					intL = intL && !(teL > best.t);
-					intR = intR && !(teR > best.t);
-				}
-				int next = -1;
-				if (intL && intR) {
-					bool lfirst = teL <= teR;
-					next = lfirst ? codeL : codeR;
-					if (sp < STACK) {  // the host rejects trees deeper than the stack
-						stk[sp][tid] = lfirst ? codeR : codeL;
-						sp++;
+			const int take = min(nidle, cend - cnext);
+			if (take > 0) {
+				const int slot = __popcll(idle & below);
+				if (!busy && slot < take) {
+					j = cnext + slot;
+					float4 O = rayO[j];
+					float4 D = rayD[j];
+					if (D.w != 0.0f) {
+						hits[j] = make_float4(__int_as_float(-2), FLT_MAX, 0.0f, 0.0f);
+					}
+					else {
+						r.ox = O.x; r.oy = O.y; r.oz = O.z;
+						dx = D.x; dy = D.y; dz = D.z;
+						r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
+						r.nx = (__float_as_uint(r.ix) >> 31) != 0;
+						r.ny = (__float_as_uint(r.iy) >> 31) != 0;
+						r.nz = (__float_as_uint(r.iz) >> 31) != 0;
+						// Position-space slack for culling: 2^-14 of the largest coordinate magnitude in play.
+						float scale = fmaxf(fmaxf(sc.sceneAbsMax, fabsf(r.ox)), fmaxf(fabsf(r.oy), fabsf(r.oz)));
+						float eps = scale * 6.103515625e-05f;
+						r.mx = eps * fabsf(r.ix); r.my = eps * fabsf(r.iy); r.mz = eps * fabsf(r.iz);
+						best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
+						found = false;
+						sp = 0;
+						cur = 0;
+						pend0 = pend1 = -1;
+						busy = true;
+						// Rays no triangle can accept are answered without traversal.  A zero direction (the
+						// reference produces one when a diffuse offset cancels the normal, src/Triangle.cpp:115)
+						// makes n.d = +-0, so t is +-inf or NaN and the hit point NaN; a non-finite direction or
+						// a NaN origin makes t NaN or zero.  Triangle::hit rejects all of these
+						// (src/Triangle.cpp:28-29,84), yet BVH::hit would hand it a large part of the tree.
+						if (!EXHAUSTIVE) {
+							const bool zero = (dx == 0.0f) & (dy == 0.0f) & (dz == 0.0f);
+							const bool finite = (fabsf(dx) <= FLT_MAX) & (fabsf(dy) <= FLT_MAX) & (fabsf(dz) <= FLT_MAX) &
+												(r.ox == r.ox) & (r.oy == r.oy) & (r.oz == r.oz);
+							if (zero | !finite) cur = -1;
+						}
 					}
 				}
-				else if (intL) next = codeL;
-				else if (intR) next = codeR;
-				else if (sp > 0) {
-					sp--;
-					next = stk[sp][tid];
-				}
-				cur = next;
+				cnext += take;
 			}
+		}
+		const bool canWalk = busy && cur >= 0 && pend0 < 0;
+		const unsigned long long mWalk = __ballot(canWalk);
+		const unsigned long long mPark = __ballot(busy && pend0 >= 0);
+		if (mWalk == 0ull && mPark == 0ull) {
+			if (__ballot(busy) == 0ull) {
+				if (!more) break;
+				continue;
+			}
+		}
+		else if (__popcll(mPark) >= triBatch || mWalk == 0ull) {
+			// triangle phase; a second round serves the lanes that parked two leaves
+			for (int rep = 0; rep < 2; ++rep) {
+				if (busy && pend0 >= 0) {
+					if (STATS) triTests++;
+					found |= tri_test(sc.triHit, pend0, r.ox, r.oy, r.oz, dx, dy, dz, best);
+					pend0 = pend1;
+					pend1 = -1;
+					if (ANYHIT && found) {
+						pend0 = -1;
+						cur = -1;
+					}
+				}
+				if (__ballot(busy && pend0 >= 0) == 0ull) break;
+			}
+		}
+		else if (canWalk) {
+			const float4* P = sc.pairs + (size_t)cur * 4;
+			float4 lmin = P[0], lmax = P[1], rmin = P[2], rmax = P[3];
+			int codeL = __float_as_int(lmin.w);
+			int codeR = __float_as_int(rmin.w);
+			float teL, txL, teR, txR;
+			bool hitL = box_test(r, lmin, lmax, teL, txL) && codeL != 0;
+			bool hitR = box_test(r, rmin, rmax, teR, txR) && codeR != 0;
+			if (STATS) nodeTests += (codeL != 0) + (codeR != 0);
+			if (!EXHAUSTIVE) {
+				hitL = hitL && !(txL < 0.001f) && !(teL > best.t);
+				hitR = hitR && !(txR < 0.001f) && !(teR > best.t);
+			}
+			if (hitL && codeL < 0) pend0 = ~codeL;
+			if (hitR && codeR < 0) {
+				if (pend0 < 0) pend0 = ~codeR;
+				else pend1 = ~codeR;
+			}
+			const bool intL = hitL && codeL > 0;
+			const bool intR = hitR && codeR > 0;
+			int next = -1;
+			if (intL && intR) {
+				bool lfirst = teL <= teR;
+				next = lfirst ? codeL : codeR;
+				if (sp < STACK) {  // the host rejects trees deeper than the stack
+					stk[sp][tid] = lfirst ? codeR : codeL;
+					if (STATS) stkT[sp][tid] = lfirst ? teR : teL;
+					sp++;
+				}
+			}
+			else if (intL) next = codeL;
+			else if (intR) next = codeR;
+			else if (sp > 0) {
+				sp--;
+				next = stk[sp][tid];
+				if (STATS) {
+					pops++;
+					if (stkT[sp][tid] > best.t) popsBeyond++;
+				}
+			}
+			cur = next;
+		}
+		if (busy && cur < 0 && pend0 < 0) {
 			int id = found ? (ANYHIT ? 0 : best.rank) : -1;
 			hits[j] = make_float4(__int_as_float(id), best.t, best.alpha, best.beta);
+			busy = false;
 		}
 	}
 	if (STATS) {
@@ -425,10 +510,14 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 		for (int off = 32; off > 0; off >>= 1) {
 			nodeTests += __shfl_down(nodeTests, off, 64);
 			triTests += __shfl_down(triTests, off, 64);
+			pops += __shfl_down(pops, off, 64);
+			popsBeyond += __shfl_down(popsBeyond, off, 64);
 		}
-		if ((tid & 63) == 0) {
+		if (lane == 0) {
 			atomicAdd(&stats[0], (unsigned long long)nodeTests);
 			atomicAdd(&stats[1], (unsigned long long)triTests);
+			atomicAdd(&stats[2], (unsigned long long)pops);
+			atomicAdd(&stats[3], (unsigned long long)popsBeyond);
 		}
 	}
 }
@@ -454,12 +543,14 @@ __device__ __forceinline__ void scatter_offset(const DevScene& sc, uint32_t key,
 	oz = 0.0f * st + ct * 1.0f;
 }
 
-__global__ __launch_bounds__(256) void k_shade(DevScene sc, int level, const float4* __restrict__ rayO,
+constexpr int SHADE_THREADS = 1024;  // 16 waves share one queue-tail atomic
+
+__global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level, const float4* __restrict__ rayO,
 											   const float4* __restrict__ rayD, const float4* __restrict__ hits, int n,
 											   float4* __restrict__ A, int4* __restrict__ B, float4* __restrict__ C,
 											   float4* __restrict__ nRayO, float4* __restrict__ nRayD,
 											   unsigned* __restrict__ cnt, unsigned nextCap) {
-	const int j = blockIdx.x * 256 + threadIdx.x;
+	const int j = blockIdx.x * SHADE_THREADS + threadIdx.x;
 	const int S = sc.nSpec, Dn = sc.nDiff;
 	int kind = KIND_LEAF;
 	int flags = 0;
@@ -549,8 +640,15 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, int level, const flo
 		}
 	}
 
-	// ---- queue slots for the children: per-kind ballots + popcounts give each lane its offset
+	// ---- queue slots for the children.  Inside a wave, per-kind ballots + popcounts give each lane its
+	// offset; the 16 wave totals of the block are scanned in LDS and the block claims its range of the
+	// next level's queue with a single atomic (one word takes only ~90 atomics per microsecond, so one
+	// atomic per wave would bound the kernel).
+	__shared__ unsigned s_tot[SHADE_THREADS / 64];
+	__shared__ unsigned s_base[SHADE_THREADS / 64];
+	__shared__ unsigned s_stat[3][SHADE_THREADS / 64];
 	const unsigned lane = threadIdx.x & 63;
+	const unsigned wave = threadIdx.x >> 6;
 	const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 	unsigned long long bm = __ballot(kind == KIND_METAL);
 	unsigned long long bt = __ballot(kind == KIND_TRANSP);
@@ -559,12 +657,31 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, int level, const flo
 					  (unsigned)__popcll(bd & lt) * (unsigned)(S + Dn);
 	unsigned total = (unsigned)__popcll(bm) * (unsigned)S + (unsigned)__popcll(bt) * (unsigned)(S + 1) +
 					 (unsigned)__popcll(bd) * (unsigned)(S + Dn);
-	unsigned waveBase = 0;
-	if (lane == 0 && total) waveBase = atomicAdd(&cnt[0], total);
-	waveBase = __shfl(waveBase, 0, 64);
-	const unsigned childBase = waveBase + offset;
-
 	unsigned long long bdead = __ballot(dead != 0), bsh = __ballot(shaded != 0), bf = __ballot(fetches != 0);
+	if (lane == 0) {
+		s_tot[wave] = total;
+		s_stat[0][wave] = (unsigned)__popcll(bdead);
+		s_stat[1][wave] = (unsigned)__popcll(bsh);
+		s_stat[2][wave] = (unsigned)__popcll(bf);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned run = 0, d = 0, sh = 0, f = 0;
+		for (int w = 0; w < SHADE_THREADS / 64; ++w) {
+			s_base[w] = run;
+			run += s_tot[w];
+			d += s_stat[0][w];
+			sh += s_stat[1][w];
+			f += s_stat[2][w];
+		}
+		unsigned base = run ? atomicAdd(&cnt[0], run) : 0u;
+		for (int w = 0; w < SHADE_THREADS / 64; ++w) s_base[w] += base;
+		if (d) atomicAdd(&cnt[1], d);
+		if (sh) atomicAdd(&cnt[2], sh);
+		if (f) atomicAdd(&cnt[3], f);
+	}
+	__syncthreads();
+	const unsigned childBase = s_base[wave] + offset;
 
 	if (nchild) {
 		if (childBase + (unsigned)nchild > nextCap) {
@@ -634,12 +751,6 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, int level, const flo
 		A[j] = make_float4(val.x, val.y, val.z, 0.0f);
 		B[j] = make_int4((int)childBase, kind | flags, __float_as_int(scalar), 0);
 		if (flags & FLAG_TEX) C[j] = make_float4(texel.x, texel.y, texel.z, 0.0f);
-	}
-	if (lane == 0) {
-		unsigned d = (unsigned)__popcll(bdead), s = (unsigned)__popcll(bsh), f = (unsigned)__popcll(bf);
-		if (d) atomicAdd(&cnt[1], d);
-		if (s) atomicAdd(&cnt[2], s);
-		if (f) atomicAdd(&cnt[3], f);
 	}
 }
 
@@ -830,6 +941,8 @@ struct EventPair {
 
 struct rtx_scene {
 	int device = 0;
+	int numCUs = 256;
+	int traceRefill = TRACE_REFILL, traceChunk = TRACE_CHUNK, traceBlocksPerCU = 8, traceTriBatch = 16;  // tunables (RTX_TRACE_* env)
 	hipStream_t stream = nullptr;
 	hipStream_t ownStream = nullptr;
 	// parameters
@@ -851,6 +964,7 @@ struct rtx_scene {
 	std::vector<int> rankOf;  // triangle index -> candidate rank
 	float sceneAbsMax = 0.0f;
 	int treeDepth = 0;
+	int stackNeed = 32;  // deepest interior node: the traversal pushes at most once per interior level
 	uint32_t numPairs = 0;
 	// device
 	DevBuf<float4> dPairs, dTriHit, dTriShade;
@@ -885,7 +999,8 @@ struct rtx_scene {
 namespace {
 
 constexpr int MAX_DEPTH = 15;
-constexpr int CNT_STRIDE = 8;
+constexpr int CNT_STRIDE = 8;   // per level: 0 queue length, 1 dead, 2 shaded, 3 texel fetches, 4 overflow flag, 5 trace cursor
+constexpr int WORK_SLOT = 5;
 
 int num_tiles(const rtx_scene* s) {
 	int tx = (s->width + TILE - 1) / TILE, ty = (s->height + TILE - 1) / TILE;
@@ -983,9 +1098,9 @@ int ensure_ready(rtx_scene* s, bool needCamera) {
 	}
 	if (!s->dCounts.p) {
 		HIPCHK(s->dCounts.alloc((MAX_DEPTH + 2) * CNT_STRIDE));
-		HIPCHK(s->dStats.alloc(2));
+		HIPCHK(s->dStats.alloc(4));
 		HIPCHK(hipHostMalloc((void**)&s->hCounts, (MAX_DEPTH + 2) * CNT_STRIDE * sizeof(unsigned), hipHostMallocDefault));
-		HIPCHK(hipHostMalloc((void**)&s->hStats, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+		HIPCHK(hipHostMalloc((void**)&s->hStats, 4 * sizeof(unsigned long long), hipHostMallocDefault));
 	}
 	return RTX_OK;
 }
@@ -1047,36 +1162,45 @@ int harvest_events(rtx_scene* s) {
 }
 
 template <bool ANYHIT, bool EXH>
-int launch_trace_t(rtx_scene* s, const DevScene& d, const float4* ro, const float4* rd, float4* hits, int n) {
-	dim3 grid((n + TRACE_THREADS - 1) / TRACE_THREADS), block(TRACE_THREADS);
-	const bool deep = s->treeDepth > 24;
+int launch_trace_t(rtx_scene* s, const DevScene& d, const float4* ro, const float4* rd, float4* hits, int n, unsigned* work) {
+	// persistent grid: enough blocks to fill every CU at full occupancy, never more than the queue needs
+	const int wanted = (n + TRACE_THREADS - 1) / TRACE_THREADS;
+	dim3 grid(std::min(wanted, s->numCUs * s->traceBlocksPerCU)), block(TRACE_THREADS);
+	const int need = s->stackNeed;
 	const bool st = s->instrumented;
 	unsigned long long* stats = s->dStats.p;
 #define RTX_LAUNCH(STK, ST) \
-	hipLaunchKernelGGL((k_trace<STK, ANYHIT, EXH, ST>), grid, block, 0, s->stream, d, ro, rd, hits, n, stats)
-	if (deep) {
-		if (st) RTX_LAUNCH(33, true); else RTX_LAUNCH(33, false);
+	hipLaunchKernelGGL((k_trace<STK, ANYHIT, EXH, ST>), grid, block, 0, s->stream, d, ro, rd, hits, n, stats, work, s->traceRefill, s->traceChunk, s->traceTriBatch)
+	if (need <= 16) {
+		if (st) RTX_LAUNCH(16, true); else RTX_LAUNCH(16, false);
+	}
+	else if (need <= 20) {
+		if (st) RTX_LAUNCH(20, true); else RTX_LAUNCH(20, false);
+	}
+	else if (need <= 24) {
+		if (st) RTX_LAUNCH(24, true); else RTX_LAUNCH(24, false);
 	}
 	else {
-		if (st) RTX_LAUNCH(25, true); else RTX_LAUNCH(25, false);
+		if (st) RTX_LAUNCH(32, true); else RTX_LAUNCH(32, false);
 	}
 #undef RTX_LAUNCH
 	HIPCHK(hipGetLastError());
 	return RTX_OK;
 }
 
+// `work` is the queue cursor of this launch: one zeroed unsigned in device memory.
 int launch_trace(rtx_scene* s, const DevScene& d, bool anyhit, bool exhaustive, const float4* ro, const float4* rd,
-				 float4* hits, int n, int level = 0) {
+				 float4* hits, int n, unsigned* work, int level = 0) {
 	if (n <= 0) return RTX_OK;
 	size_t ev;
 	int rc = begin_event(s, 0, ev, level);
 	if (rc) return rc;
 	if (exhaustive)
-		rc = launch_trace_t<false, true>(s, d, ro, rd, hits, n);
+		rc = launch_trace_t<false, true>(s, d, ro, rd, hits, n, work);
 	else if (anyhit)
-		rc = launch_trace_t<true, false>(s, d, ro, rd, hits, n);
+		rc = launch_trace_t<true, false>(s, d, ro, rd, hits, n, work);
 	else
-		rc = launch_trace_t<false, false>(s, d, ro, rd, hits, n);
+		rc = launch_trace_t<false, false>(s, d, ro, rd, hits, n, work);
 	if (rc) return rc;
 	return end_event(s, ev);
 }
@@ -1165,7 +1289,7 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 		if (rc) return rc;
 
 		if (mode == 2) {
-			rc = launch_trace(s, d, false, hitMode == 1, rayO[0], rayD[0], hit[0], b.nSamples);
+			rc = launch_trace(s, d, false, hitMode == 1, rayO[0], rayD[0], hit[0], b.nSamples, s->dCounts.p + WORK_SLOT);
 			if (rc) return rc;
 			hipLaunchKernelGGL(k_export_hits, dim3((b.nSamples + 255) / 256), dim3(256), 0, s->stream, d, b, hit[0], dIds, dTab);
 			HIPCHK(hipGetLastError());
@@ -1187,13 +1311,14 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 			C[lv] = (float4*)bump.take((size_t)n * 16);
 			if (!A[lv] || !B[lv] || !C[lv]) return fail(RTX_ERR_MEMORY, "work arena exhausted (internal sizing error)");
 			const int cur = lv & 1, nxt = cur ^ 1;
-			rc = launch_trace(s, d, lv == s->maxDepth, false, rayO[cur], rayD[cur], hit[cur], n, lv);
+			rc = launch_trace(s, d, lv == s->maxDepth, false, rayO[cur], rayD[cur], hit[cur], n,
+							  s->dCounts.p + (size_t)lv * CNT_STRIDE + WORK_SLOT, lv);
 			if (rc) return rc;
 			unsigned* cnt = s->dCounts.p + (size_t)(lv + 1) * CNT_STRIDE;
 			const unsigned nextCap = (unsigned)std::min<size_t>((size_t)n * (size_t)bmax, widestCap);
 			rc = begin_event(s, 1, ev);
 			if (rc) return rc;
-			hipLaunchKernelGGL(k_shade, dim3((n + 255) / 256), dim3(256), 0, s->stream, d, lv, rayO[cur], rayD[cur],
+			hipLaunchKernelGGL(k_shade, dim3((n + SHADE_THREADS - 1) / SHADE_THREADS), dim3(SHADE_THREADS), 0, s->stream, d, lv, rayO[cur], rayD[cur],
 							   hit[cur], n, A[lv], B[lv], C[lv], rayO[nxt], rayD[nxt], cnt, nextCap);
 			HIPCHK(hipGetLastError());
 			rc = end_event(s, ev);
@@ -1236,16 +1361,18 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 
 int finish_stats(rtx_scene* s) {
 	if (s->instrumented) {
-		HIPCHK(hipMemcpy(s->hStats, s->dStats.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(s->hStats, s->dStats.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 		s->stats.node_tests = s->hStats[0];
 		s->stats.tri_tests = s->hStats[1];
+		if (std::getenv("RTX_TRACE_DEBUG"))
+			std::fprintf(stderr, "[rtx] stack pops %llu, of which beyond the best hit at pop time %llu\n", s->hStats[2], s->hStats[3]);
 	}
 	return RTX_OK;
 }
 
 int begin_call(rtx_scene* s) {
 	std::memset(&s->stats, 0, sizeof(s->stats));
-	if (s->instrumented) HIPCHK(hipMemsetAsync(s->dStats.p, 0, 2 * sizeof(unsigned long long), s->stream));
+	if (s->instrumented) HIPCHK(hipMemsetAsync(s->dStats.p, 0, 4 * sizeof(unsigned long long), s->stream));
 	return RTX_OK;
 }
 
@@ -1271,6 +1398,12 @@ RTX_API int rtx_scene_create(rtx_scene** out, int device) {
 	rtx_scene* s = new (std::nothrow) rtx_scene();
 	if (!s) return fail(RTX_ERR_MEMORY, "out of host memory");
 	s->device = device;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->numCUs = prop.multiProcessorCount;
+	if (const char* e = std::getenv("RTX_TRACE_REFILL")) s->traceRefill = std::max(1, std::min(64, std::atoi(e)));
+	if (const char* e = std::getenv("RTX_TRACE_CHUNK")) s->traceChunk = std::max(64, std::atoi(e));
+	if (const char* e = std::getenv("RTX_TRACE_TRI_BATCH")) s->traceTriBatch = std::max(1, std::min(64, std::atoi(e)));
+	if (const char* e = std::getenv("RTX_TRACE_BLOCKS_PER_CU")) s->traceBlocksPerCU = std::max(1, std::atoi(e));
 	std::memset(&s->stats, 0, sizeof(s->stats));
 	*out = s;
 	return RTX_OK;
@@ -1359,6 +1492,7 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 	// pushed first, right popped first) numbers the leaves; that number is the tie-break rank.
 	std::vector<int> rankOf(ntri, -1);
 	std::vector<int> depthOf(n, 0);
+	int maxInteriorDepth = 0;
 	std::vector<uint8_t> seen(n, 0);
 	std::vector<int> st;
 	st.push_back(0);
@@ -1378,6 +1512,7 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 			rankOf[nd.tri] = nextRank++;
 			continue;
 		}
+		maxInteriorDepth = std::max(maxInteriorDepth, depthOf[i]);
 		for (int c : {nd.left, nd.right}) {
 			if (c > 0) {
 				if ((uint32_t)c >= n) return fail(RTX_ERR_ARG, "child index out of range");
@@ -1475,6 +1610,7 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 	s->rankOf.swap(rankOf);
 	s->numPairs = (uint32_t)npairs;
 	s->treeDepth = maxDepth + 1;  // + the root-only pair
+	s->stackNeed = maxInteriorDepth + 1;
 	s->haveBvh = true;
 	return RTX_OK;
 }
@@ -1660,7 +1796,8 @@ RTX_API int rtx_trace_rays(rtx_scene* s, int mode, uint32_t n, const float* orig
 	if (e == hipSuccess) e = hipMemcpy(dD.p, hd.data(), (size_t)n * 16, hipMemcpyHostToDevice);
 	if (e == hipSuccess) {
 		const DevScene d = make_dev_scene(s);
-		rc = launch_trace(s, d, false, mode == 1, dO.p, dD.p, dH.p, (int)n);
+		e = hipMemsetAsync(s->dCounts.p, 0, CNT_STRIDE * sizeof(unsigned), s->stream);
+		if (e == hipSuccess) rc = launch_trace(s, d, false, mode == 1, dO.p, dD.p, dH.p, (int)n, s->dCounts.p + WORK_SLOT);
 		if (rc == RTX_OK) {
 			hipLaunchKernelGGL(k_export_hits_linear, dim3((n + 255) / 256), dim3(256), 0, s->stream, d, (int)n, dH.p, dIds.p, dTab.p);
 			e = hipGetLastError();
