@@ -45,7 +45,7 @@ typedef struct rtx_scene rtx_scene; /* opaque; owns all device memory of one sce
 typedef struct rtx_stats {
 	uint64_t rays;            /* color()-equivalent queries traced (primary + secondary + last-depth occlusion) */
 	uint64_t rays_per_level[16];
-	uint64_t node_tests;      /* AABB::hit-equivalent box tests (only filled by instrumented runs) */
+	uint64_t node_tests;      /* box tests, quantised or exact (only filled by instrumented runs) */
 	uint64_t tri_tests;       /* Triangle::hit-equivalent tests   (only filled by instrumented runs) */
 	uint64_t shaded_hits;     /* hits that reached the material branch */
 	uint64_t texture_fetches; /* texture + skybox texel fetches */
@@ -55,6 +55,8 @@ typedef struct rtx_stats {
 	uint32_t trace_launches;
 	uint32_t chunks;          /* number of pixel batches the frame(s) were split into */
 	double trace_ms_per_level[16];
+	uint64_t wide_visits;     /* 64-byte nodes of the 4-wide tree fetched (only filled by instrumented runs) */
+	uint64_t leaf_fetches;    /* 64-byte triangle records fetched by the wide traversal (instrumented runs)   */
 } rtx_stats;
 
 /* ------------------------------------------------------------------ device side (librtx_hip.so) */

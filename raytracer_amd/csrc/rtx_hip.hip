@@ -79,7 +79,8 @@ constexpr int TRI_EMIT = 1, TRI_METAL = 2, TRI_TRANSP = 4;
 
 struct DevScene {
 	const float4* pairs;     // 4 x float4 per child pair: Lmin|codeL, Lmax|-, Rmin|codeR, Rmax|-
-	const float4* triHit;    // 4 x float4 per triangle in candidate-rank order
+	const float4* wide;      // 4 x float4 per node of the 4-wide quantised collapse of the tree
+	const float4* triHit;    // 4 x float4 per triangle in candidate-rank order: n, v0, v1, v2, index
 	const float4* triShade;  // 6 x float4 per triangle in candidate-rank order
 	const uint8_t* texels;
 	const int4* texDesc;     // byte offset, width, height
@@ -250,25 +251,23 @@ struct HitState {
 	int rank;
 };
 
-// Triangle::hit (src/Triangle.cpp:23-93) against the triangle stored at `rank`, folded with
-// the closest-hit rule of src/RayTracer.cpp:145 extended by the candidate-order tie break.
+// Triangle::hit (src/Triangle.cpp:23-93) for plane normal n and vertices v0, v1, v2, folded with the
+// closest-hit rule of src/RayTracer.cpp:145 extended by the candidate-order tie break.
 // Returns true when the triangle was accepted (any-hit callers stop there).
-__device__ __forceinline__ bool tri_test(const float4* __restrict__ triHit, int rank, float ox, float oy, float oz,
-										 float dx, float dy, float dz, HitState& best) {
-	const float4* T = triHit + (size_t)rank * 4;
-	float4 q0 = T[0], q1 = T[1], q2 = T[2], q3 = T[3];
-	// q0 = n.xyz v0.x | q1 = v0.yz v2.xy | q2 = v2.z a1.xyz | q3 = a2.xyz id
-	float temp = dot3w(q0.x, q0.y, q0.z, q0.w - ox, q1.x - oy, q1.y - oz);
-	float t = temp / dot3w(q0.x, q0.y, q0.z, dx, dy, dz);
+__device__ __forceinline__ bool tri_test_vals(float nx, float ny, float nz, float v0x, float v0y, float v0z, float v1x,
+											  float v1y, float v1z, float v2x, float v2y, float v2z, int rank, float ox,
+											  float oy, float oz, float dx, float dy, float dz, HitState& best) {
+	float temp = dot3w(nx, ny, nz, v0x - ox, v0y - oy, v0z - oz);
+	float t = temp / dot3w(nx, ny, nz, dx, dy, dz);
 	if (!(t > 0.001f)) return false;
 	if (t > best.t || (t == best.t && rank > best.rank)) return false;
-	float bx = (ox + t * dx) - q1.z;
-	float by = (oy + t * dy) - q1.w;
-	float bz = (oz + t * dz) - q2.x;
-	// rows (a1_i, a2_i, b_i), i = x,y,z
-	float r00 = q2.y, r01 = q3.x, r02 = bx;
-	float r10 = q2.z, r11 = q3.y, r12 = by;
-	float r20 = q2.w, r21 = q3.z, r22 = bz;
+	float bx = (ox + t * dx) - v2x;
+	float by = (oy + t * dy) - v2y;
+	float bz = (oz + t * dz) - v2z;
+	// rows (a1_i, a2_i, b_i), i = x,y,z with a1 = v0 - v2, a2 = v1 - v2 (src/Triangle.cpp:31-32)
+	float r00 = v0x - v2x, r01 = v1x - v2x, r02 = bx;
+	float r10 = v0y - v2y, r11 = v1y - v2y, r12 = by;
+	float r20 = v0z - v2z, r21 = v1z - v2z, r22 = bz;
 	// first pivot: largest |column 0|, strict >, rows tried in order 0,1,2
 	bool s1 = fabsf(r10) > fabsf(r00);
 	float mx = s1 ? fabsf(r10) : fabsf(r00);
@@ -299,6 +298,15 @@ __device__ __forceinline__ bool tri_test(const float4* __restrict__ triHit, int 
 	best.beta = beta;
 	best.rank = rank;
 	return true;
+}
+
+// The triangle stored at `rank`: q0 = n.xyz v0.x | q1 = v0.yz v1.xy | q2 = v1.z v2.xyz | q3 = id - - -
+__device__ __forceinline__ bool tri_test(const float4* __restrict__ triHit, int rank, float ox, float oy, float oz,
+										 float dx, float dy, float dz, HitState& best) {
+	const float4* T = triHit + (size_t)rank * 4;
+	float4 q0 = T[0], q1 = T[1], q2 = T[2];
+	return tri_test_vals(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, rank, ox, oy, oz, dx, dy,
+						 dz, best);
 }
 
 // Per-ray constants of the slab test.
@@ -337,16 +345,17 @@ __device__ __forceinline__ bool box_test(const RaySlab& r, float4 bmin, float4 b
 // (CHUNK consecutive rays claimed with one atomic on *work, which the host zeroes before the launch).
 // Every wave leaves the loop when the queue is exhausted and its lanes have drained.
 constexpr int TRACE_CHUNK = 256;
-constexpr int TRACE_REFILL = 32;
+constexpr int TRACE_REFILL = 16;
 
 template <int STACK, bool ANYHIT, bool EXHAUSTIVE, bool STATS>
 __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const float4* __restrict__ rayO,
 														  const float4* __restrict__ rayD, float4* __restrict__ hits,
 														  int n, unsigned long long* __restrict__ stats,
-														  unsigned* __restrict__ work, int refill, int chunk, int triBatch) {
+														  unsigned* __restrict__ work, int refill, int chunk, int triBatch,
+														  const int* __restrict__ list, const unsigned* __restrict__ listCount) {
+	// with a list: the rays to trace are list[0 .. *listCount), the ones the wide traversal set aside
+	if (list) n = (int)*listCount;
 	__shared__ int stk[STACK][TRACE_THREADS];
-	__shared__ float stkT[STATS ? STACK : 1][TRACE_THREADS];  // diagnostics only: entry bound of pushed nodes
-	unsigned pops = 0, popsBeyond = 0;
 	const int tid = threadIdx.x;
 	const unsigned lane = (unsigned)tid & 63u;
 	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -394,6 +403,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 				const int slot = __popcll(idle & below);
 				if (!busy && slot < take) {
 					j = cnext + slot;
+					if (list) j = list[j];
 					float4 O = rayO[j];
 					float4 D = rayD[j];
 					if (D.w != 0.0f) {
@@ -483,7 +493,6 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 				next = lfirst ? codeL : codeR;
 				if (sp < STACK) {  // the host rejects trees deeper than the stack
 					stk[sp][tid] = lfirst ? codeR : codeL;
-					if (STATS) stkT[sp][tid] = lfirst ? teR : teL;
 					sp++;
 				}
 			}
@@ -492,10 +501,6 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 			else if (sp > 0) {
 				sp--;
 				next = stk[sp][tid];
-				if (STATS) {
-					pops++;
-					if (stkT[sp][tid] > best.t) popsBeyond++;
-				}
 			}
 			cur = next;
 		}
@@ -510,14 +515,260 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 		for (int off = 32; off > 0; off >>= 1) {
 			nodeTests += __shfl_down(nodeTests, off, 64);
 			triTests += __shfl_down(triTests, off, 64);
-			pops += __shfl_down(pops, off, 64);
-			popsBeyond += __shfl_down(popsBeyond, off, 64);
 		}
 		if (lane == 0) {
 			atomicAdd(&stats[0], (unsigned long long)nodeTests);
 			atomicAdd(&stats[1], (unsigned long long)triTests);
-			atomicAdd(&stats[2], (unsigned long long)pops);
-			atomicAdd(&stats[3], (unsigned long long)popsBeyond);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wide traversal.
+//
+// For a ray whose three reciprocals 1/d are finite, every value the reference's slab test computes is
+// finite, and (bound - o) * (1/d) is monotone in `bound`.  A child box of the reference's tree lies
+// inside its parent's box exactly (both are min/max over vertex sets), so if the slab predicate
+// (src/BVH.cpp:14-41) passes for a leaf's own box it passes for every ancestor: for such rays the
+// candidate list of BVH::hit is exactly "the triangles whose own box passes".  The interior boxes only
+// prune, and any conservative bound may stand in for them.  This kernel therefore walks a 4-wide
+// collapse of the reference's tree (a node holds the up to four grandchildren of a binary node) whose
+// child boxes are quantised to 8 bits per coordinate inside the node's box, rounded outwards, and tested
+// inflated by the same position-space slack as the culling bounds; 64 bytes serve two levels of the
+// binary tree instead of up to 192.  Leaves are tested with the exact predicate on their exact box
+// (recomputed from the vertices) and the exact Triangle::hit, and ties go to the reference's
+// candidate order, so the result equals the reference's.  Rays with a zero or sub-2^-100 direction
+// component are set aside in a list for the binary-tree kernel above, which evaluates every ancestor.
+//
+// Node, 4 x 16 bytes:  px py pz (ex|ey<<8|ez<<16: biased exponents of the quantisation step)
+//                      lo.x[4] hi.x[4] lo.y[4] hi.y[4]      (one byte per child)
+//                      lo.z[4] hi.z[4] code0 code1
+//                      code2 code3 - -                         code > 0 node, < 0 ~rank, 0 absent
+constexpr float WIDE_MAX_INV = 1.2676506e30f;  // 2^100
+constexpr int WIDE_STACK_MAX = 52;             // binary depth <= 32 => wide depth <= 17 => 3 * 17 + 1 entries
+
+__device__ __forceinline__ float ubyte_f(unsigned v, int k) { return (float)((v >> (8 * k)) & 0xFFu); }
+
+template <int STACK, bool ANYHIT, bool STATS>
+__global__ __launch_bounds__(TRACE_THREADS) void k_trace_wide(DevScene sc, const float4* __restrict__ rayO,
+															   const float4* __restrict__ rayD, float4* __restrict__ hits,
+															   int n, unsigned long long* __restrict__ stats,
+															   unsigned* __restrict__ work, int* __restrict__ unsafeList,
+															   unsigned* __restrict__ unsafeCount, int refill, int chunk,
+															   int triBatch) {
+	__shared__ int stk[STACK][TRACE_THREADS];
+	const int tid = threadIdx.x;
+	const unsigned lane = (unsigned)tid & 63u;
+	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+	unsigned boxTests = 0, triTests = 0, nodeVisits = 0, leafFetches = 0;
+	int cnext = 0, cend = 0;
+	bool more = true;
+	int j = -1, cur = -1, sp = 0;
+	RaySlab r;
+	r.ox = r.oy = r.oz = r.ix = r.iy = r.iz = r.mx = r.my = r.mz = 0.0f;
+	r.nx = r.ny = r.nz = false;
+	float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+	HitState best;
+	best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
+	bool found = false, busy = false;
+	int pend0 = -1, pend1 = -1;
+
+	for (;;) {
+		const unsigned long long idle = __ballot(!busy);
+		const int nidle = __popcll(idle);
+		if (more && nidle >= refill) {
+			if (cnext >= cend) {
+				unsigned base = 0;
+				if (lane == 0) base = atomicAdd(work, (unsigned)chunk);
+				base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+				if (base >= (unsigned)n) {
+					more = false;
+					cnext = cend = 0;
+				}
+				else {
+					cnext = (int)base;
+					cend = min((int)base + chunk, n);
+				}
+			}
+			const int take = min(nidle, cend - cnext);
+			if (take > 0) {
+				const int slot = __popcll(idle & below);
+				if (!busy && slot < take) {
+					j = cnext + slot;
+					float4 O = rayO[j];
+					float4 D = rayD[j];
+					if (D.w != 0.0f) {
+						hits[j] = make_float4(__int_as_float(-2), FLT_MAX, 0.0f, 0.0f);
+					}
+					else {
+						r.ox = O.x; r.oy = O.y; r.oz = O.z;
+						dx = D.x; dy = D.y; dz = D.z;
+						r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
+						const bool zero = (dx == 0.0f) & (dy == 0.0f) & (dz == 0.0f);
+						const bool finite = (fabsf(dx) <= FLT_MAX) & (fabsf(dy) <= FLT_MAX) & (fabsf(dz) <= FLT_MAX) &
+											(r.ox == r.ox) & (r.oy == r.oy) & (r.oz == r.oz);
+						const bool safe = (fabsf(r.ix) <= WIDE_MAX_INV) & (fabsf(r.iy) <= WIDE_MAX_INV) & (fabsf(r.iz) <= WIDE_MAX_INV);
+						if (zero | !finite) {
+							// no triangle can accept such a ray (see k_trace)
+							hits[j] = make_float4(__int_as_float(-1), FLT_MAX, 0.0f, 0.0f);
+						}
+						else if (!safe) {
+							unsafeList[atomicAdd(unsafeCount, 1u)] = j;
+						}
+						else {
+							r.nx = (__float_as_uint(r.ix) >> 31) != 0;
+							r.ny = (__float_as_uint(r.iy) >> 31) != 0;
+							r.nz = (__float_as_uint(r.iz) >> 31) != 0;
+							float scale = fmaxf(fmaxf(sc.sceneAbsMax, fabsf(r.ox)), fmaxf(fabsf(r.oy), fabsf(r.oz)));
+							float eps = scale * 6.103515625e-05f;
+							r.mx = eps * fabsf(r.ix); r.my = eps * fabsf(r.iy); r.mz = eps * fabsf(r.iz);
+							best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
+							found = false;
+							sp = 0;
+							cur = 0;
+							pend0 = pend1 = -1;
+							busy = true;
+						}
+					}
+				}
+				cnext += take;
+			}
+		}
+		const bool canWalk = busy && pend0 < 0;
+		const unsigned long long mWalk = __ballot(canWalk);
+		const unsigned long long mPark = __ballot(busy && pend0 >= 0);
+		if (mWalk == 0ull && mPark == 0ull) {
+			if (!more) break;
+			continue;
+		}
+		if (__popcll(mPark) >= triBatch || mWalk == 0ull) {
+			// leaf phase: exact box of the triangle, exact slab predicate, exact triangle test
+			for (int rep = 0; rep < 2; ++rep) {
+				if (busy && pend0 >= 0) {
+					const float4* T = sc.triHit + (size_t)pend0 * 4;
+					float4 q0 = T[0], q1 = T[1], q2 = T[2];
+					if (STATS) leafFetches++;
+					const float v0x = q0.w, v0y = q1.x, v0z = q1.y, v1x = q1.z, v1y = q1.w, v1z = q2.x, v2x = q2.y, v2y = q2.z, v2z = q2.w;
+					// the reference's predicate on the leaf's own box (src/BVH.cpp:14-41); every value is finite here
+					const float lx = fminf(fminf(v0x, v1x), v2x), hx = fmaxf(fmaxf(v0x, v1x), v2x);
+					const float ly = fminf(fminf(v0y, v1y), v2y), hy = fmaxf(fmaxf(v0y, v1y), v2y);
+					const float lz = fminf(fminf(v0z, v1z), v2z), hz = fmaxf(fmaxf(v0z, v1z), v2z);
+					const float t0x = (lx - r.ox) * r.ix, t1x = (hx - r.ox) * r.ix;
+					const float t0y = (ly - r.oy) * r.iy, t1y = (hy - r.oy) * r.iy;
+					const float t0z = (lz - r.oz) * r.iz, t1z = (hz - r.oz) * r.iz;
+					const float tmin = fmaxf(fmaxf(r.nx ? t1x : t0x, r.ny ? t1y : t0y), r.nz ? t1z : t0z);
+					const float tmax = fminf(fminf(r.nx ? t0x : t1x, r.ny ? t0y : t1y), r.nz ? t0z : t1z);
+					const bool pass = !(tmax < tmin);
+					if (STATS) boxTests++;
+					if (pass) {
+						if (STATS) triTests++;
+						found |= tri_test_vals(q0.x, q0.y, q0.z, v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z, pend0, r.ox, r.oy,
+											   r.oz, dx, dy, dz, best);
+					}
+					pend0 = pend1;
+					pend1 = -1;
+					if (ANYHIT && found) {
+						pend0 = -1;
+						cur = -1;
+						sp = 0;
+					}
+				}
+				if (__ballot(busy && pend0 >= 0) == 0ull) break;
+			}
+		}
+		else if (canWalk) {
+			int item = 0;  // what this lane looks at next: > 0 node, < 0 ~rank of a leaf, 0 nothing yet
+			if (cur >= 0) {
+				const float4* W = sc.wide + (size_t)cur * 4;
+				float4 w0 = W[0], w1 = W[1], w2 = W[2], w3 = W[3];
+				if (STATS) nodeVisits++;
+				const unsigned ex = __float_as_uint(w0.w);
+				const float Sx = __uint_as_float((ex & 0xFFu) << 23) * r.ix;
+				const float Sy = __uint_as_float(((ex >> 8) & 0xFFu) << 23) * r.iy;
+				const float Sz = __uint_as_float(((ex >> 16) & 0xFFu) << 23) * r.iz;
+				const float Ax = (w0.x - r.ox) * r.ix, Ay = (w0.y - r.oy) * r.iy, Az = (w0.z - r.oz) * r.iz;
+				const float Anx = Ax - r.mx, Any = Ay - r.my, Anz = Az - r.mz;
+				const float Afx = Ax + r.mx, Afy = Ay + r.my, Afz = Az + r.mz;
+				const unsigned lox = __float_as_uint(w1.x), hix = __float_as_uint(w1.y), loy = __float_as_uint(w1.z),
+							   hiy = __float_as_uint(w1.w), loz = __float_as_uint(w2.x), hiz = __float_as_uint(w2.y);
+				const unsigned nxd = r.nx ? hix : lox, fxd = r.nx ? lox : hix;
+				const unsigned nyd = r.ny ? hiy : loy, fyd = r.ny ? loy : hiy;
+				const unsigned nzd = r.nz ? hiz : loz, fzd = r.nz ? loz : hiz;
+				int cd[4] = {__float_as_int(w2.z), __float_as_int(w2.w), __float_as_int(w3.x), __float_as_int(w3.y)};
+				// key = entry bound as ordered bits (it is >= 0.001), all ones for a child that is not entered
+				unsigned key[4];
+				int nh = 0;
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					float e = fmaxf(fmaxf(__fmaf_rn(ubyte_f(nxd, c), Sx, Anx), __fmaf_rn(ubyte_f(nyd, c), Sy, Any)),
+									__fmaf_rn(ubyte_f(nzd, c), Sz, Anz));
+					float x = fminf(fminf(__fmaf_rn(ubyte_f(fxd, c), Sx, Afx), __fmaf_rn(ubyte_f(fyd, c), Sy, Afy)),
+									__fmaf_rn(ubyte_f(fzd, c), Sz, Afz));
+					e = fmaxf(e, 0.001f);
+					const bool h = (cd[c] != 0) & !(x < e) & !(e > best.t);
+					key[c] = h ? __float_as_uint(e) : 0xFFFFFFFFu;
+					nh += h ? 1 : 0;
+					if (STATS) boxTests += cd[c] != 0;
+				}
+				// sorting network on (key, code), nearest first
+#define RTX_CSWAP(i, j)                                     \
+	{                                                       \
+		const bool sw = key[i] > key[j];                    \
+		const unsigned klo = min(key[i], key[j]);           \
+		const unsigned khi = max(key[i], key[j]);           \
+		const int ci = sw ? cd[j] : cd[i];                  \
+		const int cj = sw ? cd[i] : cd[j];                  \
+		key[i] = klo; key[j] = khi; cd[i] = ci; cd[j] = cj; \
+	}
+				RTX_CSWAP(0, 1)
+				RTX_CSWAP(2, 3)
+				RTX_CSWAP(0, 2)
+				RTX_CSWAP(1, 3)
+				RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+				// the nearest is looked at next, the others wait with the farthest at the bottom
+				// (the host picks STACK for the tree, so the slots exist)
+				if (nh > 3) stk[sp][tid] = cd[3];
+				if (nh > 2) stk[sp + nh - 3][tid] = cd[2];
+				if (nh > 1) stk[sp + nh - 2][tid] = cd[1];
+				sp += max(nh - 1, 0);
+				item = nh > 0 ? cd[0] : 0;
+				cur = -1;
+			}
+			if (item == 0 && sp > 0) {
+				sp--;
+				item = stk[sp][tid];
+			}
+			if (item > 0) cur = item;
+			else if (item < 0) {
+				pend0 = ~item;
+				if (sp > 0) {
+					const int nextItem = stk[sp - 1][tid];
+					if (nextItem < 0) {
+						pend1 = ~nextItem;
+						sp--;
+					}
+				}
+			}
+		}
+		if (busy && cur < 0 && pend0 < 0 && sp == 0) {
+			int id = found ? (ANYHIT ? 0 : best.rank) : -1;
+			hits[j] = make_float4(__int_as_float(id), best.t, best.alpha, best.beta);
+			busy = false;
+		}
+	}
+	if (STATS) {
+		for (int off = 32; off > 0; off >>= 1) {
+			boxTests += __shfl_down(boxTests, off, 64);
+			triTests += __shfl_down(triTests, off, 64);
+			nodeVisits += __shfl_down(nodeVisits, off, 64);
+			leafFetches += __shfl_down(leafFetches, off, 64);
+		}
+		if (lane == 0) {
+			atomicAdd(&stats[0], (unsigned long long)boxTests);
+			atomicAdd(&stats[1], (unsigned long long)triTests);
+			atomicAdd(&stats[4], (unsigned long long)nodeVisits);
+			atomicAdd(&stats[5], (unsigned long long)leafFetches);
 		}
 	}
 }
@@ -865,7 +1116,7 @@ __global__ __launch_bounds__(256) void k_export_hits(DevScene sc, Batch b, const
 	float4 h = hits[j];
 	int rank = __float_as_int(h.x);
 	size_t o = ((size_t)y * sc.width + x) * 4 + sub;
-	ids[o] = rank >= 0 ? __float_as_int(sc.triHit[(size_t)rank * 4 + 3].w) : -1;
+	ids[o] = rank >= 0 ? __float_as_int(sc.triHit[(size_t)rank * 4 + 3].x) : -1;
 	if (tab) {
 		tab[o * 3 + 0] = h.y;
 		tab[o * 3 + 1] = h.z;
@@ -879,7 +1130,7 @@ __global__ __launch_bounds__(256) void k_export_hits_linear(DevScene sc, int n, 
 	if (j >= n) return;
 	float4 h = hits[j];
 	int rank = __float_as_int(h.x);
-	ids[j] = rank >= 0 ? __float_as_int(sc.triHit[(size_t)rank * 4 + 3].w) : -1;
+	ids[j] = rank >= 0 ? __float_as_int(sc.triHit[(size_t)rank * 4 + 3].x) : -1;
 	if (tab) {
 		tab[(size_t)j * 3 + 0] = h.y;
 		tab[(size_t)j * 3 + 1] = h.z;
@@ -942,7 +1193,7 @@ struct EventPair {
 struct rtx_scene {
 	int device = 0;
 	int numCUs = 256;
-	int traceRefill = TRACE_REFILL, traceChunk = TRACE_CHUNK, traceBlocksPerCU = 8, traceTriBatch = 16;  // tunables (RTX_TRACE_* env)
+	int traceRefill = TRACE_REFILL, traceChunk = TRACE_CHUNK, traceBlocksPerCU = 8, traceTriBatch = 24;  // tunables (RTX_TRACE_* env)
 	hipStream_t stream = nullptr;
 	hipStream_t ownStream = nullptr;
 	// parameters
@@ -965,9 +1216,13 @@ struct rtx_scene {
 	float sceneAbsMax = 0.0f;
 	int treeDepth = 0;
 	int stackNeed = 32;  // deepest interior node: the traversal pushes at most once per interior level
+	int wideStackNeed = 52;  // wide traversal: entries waiting when every child of every node on a path is hit
+	bool wideOk = false;     // the tree satisfies what k_trace_wide relies on
+	bool forceBinary = false;  // RTX_TRACE_BINARY=1: binary-tree kernel only (for comparisons)
+	uint32_t numWide = 0;
 	uint32_t numPairs = 0;
 	// device
-	DevBuf<float4> dPairs, dTriHit, dTriShade;
+	DevBuf<float4> dPairs, dWide, dTriHit, dTriShade;
 	DevBuf<uint8_t> dTexels;
 	DevBuf<int4> dTexDesc;
 	DevBuf<float> dTables;  // cos[512] sin[512] gamma[256]
@@ -984,7 +1239,7 @@ struct rtx_scene {
 
 	~rtx_scene() {
 		(void)hipSetDevice(device);
-		dPairs.release(); dTriHit.release(); dTriShade.release(); dTexels.release(); dTexDesc.release();
+		dPairs.release(); dWide.release(); dTriHit.release(); dTriShade.release(); dTexels.release(); dTexDesc.release();
 		dTables.release(); dAccumOwn.release(); arena.release(); dCounts.release(); dStats.release();
 		if (hCounts) (void)hipHostFree(hCounts);
 		if (hStats) (void)hipHostFree(hStats);
@@ -999,8 +1254,7 @@ struct rtx_scene {
 namespace {
 
 constexpr int MAX_DEPTH = 15;
-constexpr int CNT_STRIDE = 8;   // per level: 0 queue length, 1 dead, 2 shaded, 3 texel fetches, 4 overflow flag, 5 trace cursor
-constexpr int WORK_SLOT = 5;
+constexpr int CNT_STRIDE = 8;   // per level: 0 queue length, 1 dead, 2 shaded, 3 texel fetches, 4 overflow flag, 5-7 trace cursors
 
 int num_tiles(const rtx_scene* s) {
 	int tx = (s->width + TILE - 1) / TILE, ty = (s->height + TILE - 1) / TILE;
@@ -1020,6 +1274,7 @@ DevScene make_dev_scene(const rtx_scene* s) {
 	DevScene d;
 	std::memset(&d, 0, sizeof(d));
 	d.pairs = s->dPairs.p;
+	d.wide = s->dWide.p;
 	d.triHit = s->dTriHit.p;
 	d.triShade = s->dTriShade.p;
 	d.texels = s->dTexels.p;
@@ -1098,9 +1353,9 @@ int ensure_ready(rtx_scene* s, bool needCamera) {
 	}
 	if (!s->dCounts.p) {
 		HIPCHK(s->dCounts.alloc((MAX_DEPTH + 2) * CNT_STRIDE));
-		HIPCHK(s->dStats.alloc(4));
+		HIPCHK(s->dStats.alloc(8));
 		HIPCHK(hipHostMalloc((void**)&s->hCounts, (MAX_DEPTH + 2) * CNT_STRIDE * sizeof(unsigned), hipHostMallocDefault));
-		HIPCHK(hipHostMalloc((void**)&s->hStats, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+		HIPCHK(hipHostMalloc((void**)&s->hStats, 8 * sizeof(unsigned long long), hipHostMallocDefault));
 	}
 	return RTX_OK;
 }
@@ -1117,7 +1372,7 @@ double worst_bytes_per_sample(const rtx_scene* s) {
 		sum += pw;
 		if (d < s->maxDepth) pw *= bmax;
 	}
-	return sum * NODE_BYTES + 2.0 * pw * RAY_BYTES;
+	return sum * NODE_BYTES + pw * (2.0 * RAY_BYTES + 4.0);
 }
 
 struct EventScope {
@@ -1161,16 +1416,24 @@ int harvest_events(rtx_scene* s) {
 	return RTX_OK;
 }
 
+// Slots of a level's counter block (CNT_STRIDE unsigned, zeroed at the start of a pixel batch).
+constexpr int WORK_SLOT = 5;     // queue cursor of the wide traversal
+constexpr int UNSAFE_SLOT = 6;   // number of rays set aside for the binary-tree kernel
+constexpr int WORK2_SLOT = 7;    // queue cursor of the binary-tree kernel
+
+// The binary-tree kernel (every ancestor box evaluated as the reference does).  With a list it
+// traces list[0 .. *listCount); the count lives on the device, so the grid is a fixed small one.
 template <bool ANYHIT, bool EXH>
-int launch_trace_t(rtx_scene* s, const DevScene& d, const float4* ro, const float4* rd, float4* hits, int n, unsigned* work) {
-	// persistent grid: enough blocks to fill every CU at full occupancy, never more than the queue needs
-	const int wanted = (n + TRACE_THREADS - 1) / TRACE_THREADS;
-	dim3 grid(std::min(wanted, s->numCUs * s->traceBlocksPerCU)), block(TRACE_THREADS);
+int launch_exact_t(rtx_scene* s, const DevScene& d, const float4* ro, const float4* rd, float4* hits, int n, unsigned* work,
+				   const int* list, const unsigned* listCount) {
+	const int wanted = list ? s->numCUs : (n + TRACE_THREADS - 1) / TRACE_THREADS;
+	dim3 grid(std::max(1, std::min(wanted, s->numCUs * s->traceBlocksPerCU))), block(TRACE_THREADS);
 	const int need = s->stackNeed;
 	const bool st = s->instrumented;
 	unsigned long long* stats = s->dStats.p;
-#define RTX_LAUNCH(STK, ST) \
-	hipLaunchKernelGGL((k_trace<STK, ANYHIT, EXH, ST>), grid, block, 0, s->stream, d, ro, rd, hits, n, stats, work, s->traceRefill, s->traceChunk, s->traceTriBatch)
+#define RTX_LAUNCH(STK, ST)                                                                                              \
+	hipLaunchKernelGGL((k_trace<STK, ANYHIT, EXH, ST>), grid, block, 0, s->stream, d, ro, rd, hits, n, stats, work,      \
+					   s->traceRefill, s->traceChunk, s->traceTriBatch, list, listCount)
 	if (need <= 16) {
 		if (st) RTX_LAUNCH(16, true); else RTX_LAUNCH(16, false);
 	}
@@ -1188,19 +1451,56 @@ int launch_trace_t(rtx_scene* s, const DevScene& d, const float4* ro, const floa
 	return RTX_OK;
 }
 
-// `work` is the queue cursor of this launch: one zeroed unsigned in device memory.
+template <bool ANYHIT>
+int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float4* rd, float4* hits, int n, unsigned* work,
+				  int* unsafeList, unsigned* unsafeCount) {
+	const int wanted = (n + TRACE_THREADS - 1) / TRACE_THREADS;
+	dim3 grid(std::min(wanted, s->numCUs * s->traceBlocksPerCU)), block(TRACE_THREADS);
+	const int need = s->wideStackNeed;
+	const bool st = s->instrumented;
+	unsigned long long* stats = s->dStats.p;
+#define RTX_LAUNCH(STK, ST)                                                                                              \
+	hipLaunchKernelGGL((k_trace_wide<STK, ANYHIT, ST>), grid, block, 0, s->stream, d, ro, rd, hits, n, stats, work,      \
+					   unsafeList, unsafeCount, s->traceRefill, s->traceChunk, s->traceTriBatch)
+	if (need <= 24) {
+		if (st) RTX_LAUNCH(24, true); else RTX_LAUNCH(24, false);
+	}
+	else if (need <= 32) {
+		if (st) RTX_LAUNCH(32, true); else RTX_LAUNCH(32, false);
+	}
+	else if (need <= 40) {
+		if (st) RTX_LAUNCH(40, true); else RTX_LAUNCH(40, false);
+	}
+	else {
+		if (st) RTX_LAUNCH(WIDE_STACK_MAX, true); else RTX_LAUNCH(WIDE_STACK_MAX, false);
+	}
+#undef RTX_LAUNCH
+	HIPCHK(hipGetLastError());
+	return RTX_OK;
+}
+
+// One queue of rays -> hit records.  `cnt` is the level's zeroed counter block, `unsafeList` room for n ints.
+// Production: wide traversal, then the binary-tree kernel over the rays the wide one set aside.
+// Exhaustive: the binary-tree kernel without culling over the whole queue.
 int launch_trace(rtx_scene* s, const DevScene& d, bool anyhit, bool exhaustive, const float4* ro, const float4* rd,
-				 float4* hits, int n, unsigned* work, int level = 0) {
+				 float4* hits, int n, unsigned* cnt, int* unsafeList, int level = 0) {
 	if (n <= 0) return RTX_OK;
 	size_t ev;
 	int rc = begin_event(s, 0, ev, level);
 	if (rc) return rc;
 	if (exhaustive)
-		rc = launch_trace_t<false, true>(s, d, ro, rd, hits, n, work);
-	else if (anyhit)
-		rc = launch_trace_t<true, false>(s, d, ro, rd, hits, n, work);
-	else
-		rc = launch_trace_t<false, false>(s, d, ro, rd, hits, n, work);
+		rc = launch_exact_t<false, true>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, nullptr, nullptr);
+	else if (!s->wideOk || s->forceBinary)
+		rc = anyhit ? launch_exact_t<true, false>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, nullptr, nullptr)
+					: launch_exact_t<false, false>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, nullptr, nullptr);
+	else if (anyhit) {
+		rc = launch_wide_t<true>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, unsafeList, cnt + UNSAFE_SLOT);
+		if (rc == RTX_OK) rc = launch_exact_t<true, false>(s, d, ro, rd, hits, n, cnt + WORK2_SLOT, unsafeList, cnt + UNSAFE_SLOT);
+	}
+	else {
+		rc = launch_wide_t<false>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, unsafeList, cnt + UNSAFE_SLOT);
+		if (rc == RTX_OK) rc = launch_exact_t<false, false>(s, d, ro, rd, hits, n, cnt + WORK2_SLOT, unsafeList, cnt + UNSAFE_SLOT);
+	}
 	if (rc) return rc;
 	return end_event(s, ev);
 }
@@ -1239,16 +1539,16 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 	const int bmax = std::max(s->nSpec + s->nDiff, s->nSpec + 1);
 
 	// batch size from the arena budget
-	double perSample = (mode == 2) ? (double)(NODE_BYTES + RAY_BYTES) : worst_bytes_per_sample(s);
+	double perSample = (mode == 2) ? (double)(NODE_BYTES + 2 * RAY_BYTES + 4) : worst_bytes_per_sample(s);
 	size_t freeB = 0, totalB = 0;
 	HIPCHK(hipMemGetInfo(&freeB, &totalB));
 	size_t budget = s->arenaLimit ? (size_t)s->arenaLimit : (size_t)((double)(freeB + s->arena.n) * 0.6);
-	double needAll = perSample * (double)totalBlocks * SAMPLES_PER_BLOCK + (double)(MAX_DEPTH + 4) * 4096;
+	double needAll = perSample * (double)totalBlocks * SAMPLES_PER_BLOCK + (double)(MAX_DEPTH + 8) * 4096;
 	size_t want = (size_t)std::min((double)budget, needAll);
-	long long blocksPerBatch = (long long)(((double)want - (double)(MAX_DEPTH + 4) * 4096) / (perSample * SAMPLES_PER_BLOCK));
+	long long blocksPerBatch = (long long)(((double)want - (double)(MAX_DEPTH + 8) * 4096) / (perSample * SAMPLES_PER_BLOCK));
 	if (blocksPerBatch < 1) {
 		blocksPerBatch = 1;
-		want = (size_t)(perSample * SAMPLES_PER_BLOCK) + (MAX_DEPTH + 4) * 4096;
+		want = (size_t)(perSample * SAMPLES_PER_BLOCK) + (MAX_DEPTH + 8) * 4096;
 	}
 	if (blocksPerBatch > totalBlocks) blocksPerBatch = totalBlocks;
 	// keep sample indices inside int32
@@ -1272,9 +1572,11 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 		size_t widestCap = (size_t)b.nSamples;
 		for (int i = 0; i < levels; ++i) widestCap *= (size_t)bmax;
 		const size_t setBytes = ((widestCap * 16 + 255) & ~(size_t)255);
+		const size_t listBytes = ((widestCap * 4 + 255) & ~(size_t)255);
 		Bump bump{s->arena.p, s->arena.n, 0, s->arena.n};
-		if (6 * setBytes > bump.cap) return fail(RTX_ERR_MEMORY, "work arena too small for one pixel block");
-		bump.hi = bump.cap - 6 * setBytes;
+		if (6 * setBytes + listBytes > bump.cap) return fail(RTX_ERR_MEMORY, "work arena too small for one pixel block");
+		bump.hi = bump.cap - 6 * setBytes - listBytes;
+		int* unsafeList = (int*)(bump.base + bump.hi + 6 * setBytes);
 		float4* rayO[2] = {(float4*)(bump.base + bump.hi), (float4*)(bump.base + bump.hi + 3 * setBytes)};
 		float4* rayD[2] = {(float4*)(bump.base + bump.hi + setBytes), (float4*)(bump.base + bump.hi + 4 * setBytes)};
 		float4* hit[2] = {(float4*)(bump.base + bump.hi + 2 * setBytes), (float4*)(bump.base + bump.hi + 5 * setBytes)};
@@ -1289,7 +1591,7 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 		if (rc) return rc;
 
 		if (mode == 2) {
-			rc = launch_trace(s, d, false, hitMode == 1, rayO[0], rayD[0], hit[0], b.nSamples, s->dCounts.p + WORK_SLOT);
+			rc = launch_trace(s, d, false, hitMode == 1, rayO[0], rayD[0], hit[0], b.nSamples, s->dCounts.p, unsafeList);
 			if (rc) return rc;
 			hipLaunchKernelGGL(k_export_hits, dim3((b.nSamples + 255) / 256), dim3(256), 0, s->stream, d, b, hit[0], dIds, dTab);
 			HIPCHK(hipGetLastError());
@@ -1312,7 +1614,7 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 			if (!A[lv] || !B[lv] || !C[lv]) return fail(RTX_ERR_MEMORY, "work arena exhausted (internal sizing error)");
 			const int cur = lv & 1, nxt = cur ^ 1;
 			rc = launch_trace(s, d, lv == s->maxDepth, false, rayO[cur], rayD[cur], hit[cur], n,
-							  s->dCounts.p + (size_t)lv * CNT_STRIDE + WORK_SLOT, lv);
+							  s->dCounts.p + (size_t)lv * CNT_STRIDE, unsafeList, lv);
 			if (rc) return rc;
 			unsigned* cnt = s->dCounts.p + (size_t)(lv + 1) * CNT_STRIDE;
 			const unsigned nextCap = (unsigned)std::min<size_t>((size_t)n * (size_t)bmax, widestCap);
@@ -1361,18 +1663,18 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 
 int finish_stats(rtx_scene* s) {
 	if (s->instrumented) {
-		HIPCHK(hipMemcpy(s->hStats, s->dStats.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(s->hStats, s->dStats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 		s->stats.node_tests = s->hStats[0];
 		s->stats.tri_tests = s->hStats[1];
-		if (std::getenv("RTX_TRACE_DEBUG"))
-			std::fprintf(stderr, "[rtx] stack pops %llu, of which beyond the best hit at pop time %llu\n", s->hStats[2], s->hStats[3]);
+		s->stats.wide_visits = s->hStats[4];
+		s->stats.leaf_fetches = s->hStats[5];
 	}
 	return RTX_OK;
 }
 
 int begin_call(rtx_scene* s) {
 	std::memset(&s->stats, 0, sizeof(s->stats));
-	if (s->instrumented) HIPCHK(hipMemsetAsync(s->dStats.p, 0, 4 * sizeof(unsigned long long), s->stream));
+	if (s->instrumented) HIPCHK(hipMemsetAsync(s->dStats.p, 0, 8 * sizeof(unsigned long long), s->stream));
 	return RTX_OK;
 }
 
@@ -1404,6 +1706,7 @@ RTX_API int rtx_scene_create(rtx_scene** out, int device) {
 	if (const char* e = std::getenv("RTX_TRACE_CHUNK")) s->traceChunk = std::max(64, std::atoi(e));
 	if (const char* e = std::getenv("RTX_TRACE_TRI_BATCH")) s->traceTriBatch = std::max(1, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_TRACE_BLOCKS_PER_CU")) s->traceBlocksPerCU = std::max(1, std::atoi(e));
+	if (const char* e = std::getenv("RTX_TRACE_BINARY")) s->forceBinary = std::atoi(e) != 0;
 	std::memset(&s->stats, 0, sizeof(s->stats));
 	*out = s;
 	return RTX_OK;
@@ -1568,6 +1871,117 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 		if (nd.right > 0) put(k + 1, 1, nd.right, code_of(nd.right));
 	}
 
+	// Pass 3: the 4-wide collapse walked by k_trace_wide.  The wide node of a binary interior node X holds
+	// X's grandchildren, and X's children where those are leaves.  It may only be used when boxes nest
+	// exactly and leaf boxes are the triangles' own bounds, which is what the reference's builder
+	// produces (src/BVH.cpp:60-160); a tree that breaks either rule is walked by the binary kernel alone.
+	bool wideOk = true;
+	for (uint32_t i = 0; i < n && wideOk; ++i) {
+		const HostNode& nd = N[i];
+		if (!seen[i]) continue;
+		if (nd.tri >= 0) {
+			const HostTri& t = s->tris[nd.tri];
+			for (int c = 0; c < 3; ++c) {
+				float lo = std::min(std::min(t.v[0][c], t.v[1][c]), t.v[2][c]);
+				float hi = std::max(std::max(t.v[0][c], t.v[1][c]), t.v[2][c]);
+				if (!(nd.bmin[c] == lo) || !(nd.bmax[c] == hi)) wideOk = false;
+			}
+			continue;
+		}
+		for (int ch : {nd.left, nd.right}) {
+			if (ch <= 0) continue;
+			for (int c = 0; c < 3; ++c)
+				if (!(N[ch].bmin[c] >= nd.bmin[c]) || !(N[ch].bmax[c] <= nd.bmax[c])) wideOk = false;
+		}
+	}
+	std::vector<float4> wide;
+	int wideStackNeed = 1;
+	if (wideOk) {
+		auto has_children = [&](int i) { return N[i].tri < 0 && (N[i].left > 0 || N[i].right > 0); };
+		// breadth-first numbering of the binary nodes that own a wide node
+		std::vector<int> wideOf(n, 0), worder;
+		auto members = [&](int x, int out[4]) {
+			int k = 0;
+			for (int ch : {N[x].left, N[x].right}) {
+				if (ch <= 0) continue;
+				if (N[ch].tri >= 0) out[k++] = ch;
+				else
+					for (int g : {N[ch].left, N[ch].right})
+						if (g > 0 && (N[g].tri >= 0 || has_children(g))) out[k++] = g;
+			}
+			return k;
+		};
+		worder.push_back(0);
+		for (size_t h = 0; h < worder.size(); ++h) {
+			int m[4];
+			int k = N[worder[h]].tri >= 0 ? 0 : members(worder[h], m);
+			for (int c = 0; c < k; ++c)
+				if (N[m[c]].tri < 0) {
+					wideOf[m[c]] = (int)worder.size();
+					worder.push_back(m[c]);
+				}
+		}
+		wide.assign(worder.size() * 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+		std::vector<int> need(worder.size(), 0);
+		for (size_t h = worder.size(); h-- > 0;) {
+			const int x = worder[h];
+			int m[4], k;
+			if (N[x].tri >= 0) {  // a tree that is one leaf: the root's wide node has that leaf as its only child
+				m[0] = x;
+				k = 1;
+			}
+			else k = members(x, m);
+			double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+			for (int c = 0; c < k; ++c)
+				for (int a = 0; a < 3; ++a) {
+					lo[a] = c ? std::min(lo[a], (double)N[m[c]].bmin[a]) : (double)N[m[c]].bmin[a];
+					hi[a] = c ? std::max(hi[a], (double)N[m[c]].bmax[a]) : (double)N[m[c]].bmax[a];
+				}
+			uint32_t expo = 0, q[6] = {0, 0, 0, 0, 0, 0};  // lo.x hi.x lo.y hi.y lo.z hi.z, one byte per child
+			for (int a = 0; a < 3; ++a) {
+				// smallest power-of-two step with 254 steps >= extent (one step of slack for the rounding of
+				// the double arithmetic below), as a biased float exponent in 1..254
+				int e = 1;
+				while (e < 254 && 254.0 * std::ldexp(1.0, e - 127) < hi[a] - lo[a]) ++e;
+				const double step = std::ldexp(1.0, e - 127);
+				if (254.0 * step < hi[a] - lo[a]) wideOk = false;
+				expo |= (uint32_t)e << (8 * a);
+				for (int c = 0; c < k; ++c) {
+					const double cmin = N[m[c]].bmin[a], cmax = N[m[c]].bmax[a];
+					uint32_t l = (uint32_t)std::min(255.0, std::max(0.0, std::floor((cmin - lo[a]) / step)));
+					uint32_t u = (uint32_t)std::min(255.0, std::max(0.0, std::ceil((cmax - lo[a]) / step)));
+					// A rounded double sum that compares strictly beyond a float proves the exact sum is at or
+					// beyond it; move outwards until that holds (the ends of the range hold by construction).
+					while (l > 0 && !(lo[a] + l * step < cmin)) --l;
+					while (u < 255 && !(lo[a] + u * step > cmax)) ++u;
+					q[a * 2 + 0] |= l << (8 * c);
+					q[a * 2 + 1] |= u << (8 * c);
+				}
+			}
+			int code[4] = {0, 0, 0, 0}, deepest = 0;
+			for (int c = 0; c < k; ++c) {
+				if (N[m[c]].tri >= 0) code[c] = ~rankOf[N[m[c]].tri];
+				else {
+					code[c] = wideOf[m[c]];
+					deepest = std::max(deepest, need[wideOf[m[c]]]);
+				}
+			}
+			// all children pushed, one popped and expanded while the others wait
+			need[h] = std::max(k, k - 1 + deepest);
+			auto bits = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+			wide[h * 4 + 0] = make_float4((float)lo[0], (float)lo[1], (float)lo[2], bits(expo));
+			wide[h * 4 + 1] = make_float4(bits(q[0]), bits(q[1]), bits(q[2]), bits(q[3]));
+			wide[h * 4 + 2] = make_float4(bits(q[4]), bits(q[5]), bits((uint32_t)code[0]), bits((uint32_t)code[1]));
+			wide[h * 4 + 3] = make_float4(bits((uint32_t)code[2]), bits((uint32_t)code[3]), 0.0f, 0.0f);
+		}
+		wideStackNeed = std::max(1, need[0]);
+		if (wideStackNeed > WIDE_STACK_MAX) wideOk = false;
+	}
+
+	if (std::getenv("RTX_TRACE_DEBUG"))
+		std::fprintf(stderr, "[rtx] wide tree: ok %d, %zu nodes, stack need %d (binary: %zu pairs, stack need %d)\n", (int)wideOk,
+					 wide.size() / 4, wideStackNeed, npairs, maxInteriorDepth + 1);
+
 	// Triangle records in rank order.
 	std::vector<float4> th((size_t)std::max<uint32_t>(ntri, 1) * 4), ts((size_t)std::max<uint32_t>(ntri, 1) * 6);
 	for (uint32_t i = 0; i < ntri; ++i) {
@@ -1585,9 +1999,9 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 		int32_t id = (int32_t)i;
 		std::memcpy(&idf, &id, 4);
 		th[r * 4 + 0] = make_float4(t.pn[0], t.pn[1], t.pn[2], v0[0]);
-		th[r * 4 + 1] = make_float4(v0[1], v0[2], v2[0], v2[1]);
-		th[r * 4 + 2] = make_float4(v2[2], a1[0], a1[1], a1[2]);
-		th[r * 4 + 3] = make_float4(a2[0], a2[1], a2[2], idf);
+		th[r * 4 + 1] = make_float4(v0[1], v0[2], v1[0], v1[1]);
+		th[r * 4 + 2] = make_float4(v1[2], v2[0], v2[1], v2[2]);
+		th[r * 4 + 3] = make_float4(idf, 0.0f, 0.0f, 0.0f);
 		int32_t flags = (t.emit ? TRI_EMIT : 0) | (t.metal ? TRI_METAL : 0) | (t.transp ? TRI_TRANSP : 0);
 		float texf, flagf;
 		std::memcpy(&texf, &t.tex, 4);
@@ -1603,6 +2017,13 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 	HIPCHK(hipSetDevice(s->device));
 	HIPCHK(s->dPairs.alloc(pairs.size()));
 	HIPCHK(hipMemcpy(s->dPairs.p, pairs.data(), pairs.size() * sizeof(float4), hipMemcpyHostToDevice));
+	if (wideOk) {
+		HIPCHK(s->dWide.alloc(wide.size()));
+		HIPCHK(hipMemcpy(s->dWide.p, wide.data(), wide.size() * sizeof(float4), hipMemcpyHostToDevice));
+	}
+	s->wideOk = wideOk;
+	s->wideStackNeed = wideStackNeed;
+	s->numWide = (uint32_t)(wide.size() / 4);
 	HIPCHK(s->dTriHit.alloc(th.size()));
 	HIPCHK(hipMemcpy(s->dTriHit.p, th.data(), th.size() * sizeof(float4), hipMemcpyHostToDevice));
 	HIPCHK(s->dTriShade.alloc(ts.size()));
@@ -1785,9 +2206,10 @@ RTX_API int rtx_trace_rays(rtx_scene* s, int mode, uint32_t n, const float* orig
 		hd[i] = make_float4(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2], 0.0f);
 	}
 	DevBuf<float4> dO, dD, dH;
-	DevBuf<int> dIds;
+	DevBuf<int> dIds, dList;
 	DevBuf<float> dTab;
 	hipError_t e = dO.alloc(n);
+	if (e == hipSuccess) e = dList.alloc(n);
 	if (e == hipSuccess) e = dD.alloc(n);
 	if (e == hipSuccess) e = dH.alloc(n);
 	if (e == hipSuccess) e = dIds.alloc(n);
@@ -1797,7 +2219,7 @@ RTX_API int rtx_trace_rays(rtx_scene* s, int mode, uint32_t n, const float* orig
 	if (e == hipSuccess) {
 		const DevScene d = make_dev_scene(s);
 		e = hipMemsetAsync(s->dCounts.p, 0, CNT_STRIDE * sizeof(unsigned), s->stream);
-		if (e == hipSuccess) rc = launch_trace(s, d, false, mode == 1, dO.p, dD.p, dH.p, (int)n, s->dCounts.p + WORK_SLOT);
+		if (e == hipSuccess) rc = launch_trace(s, d, false, mode == 1, dO.p, dD.p, dH.p, (int)n, s->dCounts.p, dList.p);
 		if (rc == RTX_OK) {
 			hipLaunchKernelGGL(k_export_hits_linear, dim3((n + 255) / 256), dim3(256), 0, s->stream, d, (int)n, dH.p, dIds.p, dTab.p);
 			e = hipGetLastError();
@@ -1806,7 +2228,7 @@ RTX_API int rtx_trace_rays(rtx_scene* s, int mode, uint32_t n, const float* orig
 			if (e == hipSuccess && t_alpha_beta) e = hipMemcpy(t_alpha_beta, dTab.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost);
 		}
 	}
-	dO.release(); dD.release(); dH.release(); dIds.release(); dTab.release();
+	dO.release(); dD.release(); dH.release(); dIds.release(); dTab.release(); dList.release();
 	if (e != hipSuccess) return fail(RTX_ERR_DEVICE, hipGetErrorString(e));
 	if (rc) return rc;
 	rc = harvest_events(s);
