@@ -43,6 +43,7 @@
 #include <vector>
 
 #include "../../include/rtx.h"
+#include "rtx_wide.h"
 
 #define RTX_API extern "C" __attribute__((visibility("default")))
 
@@ -561,6 +562,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_wide(DevScene sc, const
 	const unsigned lane = (unsigned)tid & 63u;
 	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
 	unsigned boxTests = 0, triTests = 0, nodeVisits = 0, leafFetches = 0;
+	unsigned walkIters = 0, leafIters = 0, walkLanes = 0, leafLanes = 0;  // wave-level, kept by lane 0
 	int cnext = 0, cend = 0;
 	bool more = true;
 	int j = -1, cur = -1, sp = 0;
@@ -640,6 +642,16 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_wide(DevScene sc, const
 		if (mWalk == 0ull && mPark == 0ull) {
 			if (!more) break;
 			continue;
+		}
+		if (STATS) {
+			if (__popcll(mPark) >= triBatch || mWalk == 0ull) {
+				leafIters++;
+				leafLanes += __popcll(mPark);
+			}
+			else {
+				walkIters++;
+				walkLanes += __popcll(mWalk);
+			}
 		}
 		if (__popcll(mPark) >= triBatch || mWalk == 0ull) {
 			// leaf phase: exact box of the triangle, exact slab predicate, exact triangle test
@@ -769,6 +781,10 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_wide(DevScene sc, const
 			atomicAdd(&stats[1], (unsigned long long)triTests);
 			atomicAdd(&stats[4], (unsigned long long)nodeVisits);
 			atomicAdd(&stats[5], (unsigned long long)leafFetches);
+			atomicAdd(&stats[2], (unsigned long long)walkIters);
+			atomicAdd(&stats[3], (unsigned long long)walkLanes);
+			atomicAdd(&stats[6], (unsigned long long)leafIters);
+			atomicAdd(&stats[7], (unsigned long long)leafLanes);
 		}
 	}
 }
@@ -1666,6 +1682,10 @@ int finish_stats(rtx_scene* s) {
 		HIPCHK(hipMemcpy(s->hStats, s->dStats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 		s->stats.node_tests = s->hStats[0];
 		s->stats.tri_tests = s->hStats[1];
+		if (std::getenv("RTX_TRACE_DEBUG"))
+			std::fprintf(stderr, "[rtx] wide: walk iterations %llu with %.1f lanes, leaf phases %llu with %.1f lanes\n", s->hStats[2],
+						 (double)s->hStats[3] / (double)std::max(1ull, s->hStats[2]), s->hStats[6],
+						 (double)s->hStats[7] / (double)std::max(1ull, s->hStats[6]));
 		s->stats.wide_visits = s->hStats[4];
 		s->stats.leaf_fetches = s->hStats[5];
 	}
@@ -1894,93 +1914,46 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 				if (!(N[ch].bmin[c] >= nd.bmin[c]) || !(N[ch].bmax[c] <= nd.bmax[c])) wideOk = false;
 		}
 	}
-	std::vector<float4> wide;
+	std::vector<float> wide;
 	int wideStackNeed = 1;
+	const char* treeKind = "none";
 	if (wideOk) {
-		auto has_children = [&](int i) { return N[i].tri < 0 && (N[i].left > 0 || N[i].right > 0); };
-		// breadth-first numbering of the binary nodes that own a wide node
-		std::vector<int> wideOf(n, 0), worder;
-		auto members = [&](int x, int out[4]) {
-			int k = 0;
-			for (int ch : {N[x].left, N[x].right}) {
-				if (ch <= 0) continue;
-				if (N[ch].tri >= 0) out[k++] = ch;
-				else
-					for (int g : {N[ch].left, N[ch].right})
-						if (g > 0 && (N[g].tri >= 0 || has_children(g))) out[k++] = g;
-			}
-			return k;
-		};
-		worder.push_back(0);
-		for (size_t h = 0; h < worder.size(); ++h) {
-			int m[4];
-			int k = N[worder[h]].tri >= 0 ? 0 : members(worder[h], m);
-			for (int c = 0; c < k; ++c)
-				if (N[m[c]].tri < 0) {
-					wideOf[m[c]] = (int)worder.size();
-					worder.push_back(m[c]);
+		// own surface-area tree over the triangles' boxes; the reference's tree if that one cannot be used
+		bool built = false;
+		const char* want = std::getenv("RTX_WIDE_TREE");
+		if (!(want && std::strcmp(want, "reference") == 0)) {
+			std::vector<float> box((size_t)ntri * 6);
+			for (uint32_t i = 0; i < ntri; ++i) {
+				const HostTri& t = s->tris[i];
+				for (int c = 0; c < 3; ++c) {
+					box[(size_t)i * 6 + c] = std::min(std::min(t.v[0][c], t.v[1][c]), t.v[2][c]);
+					box[(size_t)i * 6 + 3 + c] = std::max(std::max(t.v[0][c], t.v[1][c]), t.v[2][c]);
 				}
+			}
+			std::vector<rtxwide::BinNode> own;
+			const int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+			rtxwide::build_sah(box, (int)ntri, own, threads);
+			built = rtxwide::collapse_wide(own, rankOf, wide, wideStackNeed) && wideStackNeed <= WIDE_STACK_MAX;
+			treeKind = "surface-area";
 		}
-		wide.assign(worder.size() * 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-		std::vector<int> need(worder.size(), 0);
-		for (size_t h = worder.size(); h-- > 0;) {
-			const int x = worder[h];
-			int m[4], k;
-			if (N[x].tri >= 0) {  // a tree that is one leaf: the root's wide node has that leaf as its only child
-				m[0] = x;
-				k = 1;
+		if (!built) {
+			std::vector<rtxwide::BinNode> ref(n);
+			for (uint32_t i = 0; i < n; ++i) {
+				std::memcpy(ref[i].bmin, N[i].bmin, 12);
+				std::memcpy(ref[i].bmax, N[i].bmax, 12);
+				ref[i].left = N[i].left > 0 ? N[i].left : -1;
+				ref[i].right = N[i].right > 0 ? N[i].right : -1;
+				ref[i].tri = N[i].tri >= 0 ? N[i].tri : -1;
 			}
-			else k = members(x, m);
-			double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-			for (int c = 0; c < k; ++c)
-				for (int a = 0; a < 3; ++a) {
-					lo[a] = c ? std::min(lo[a], (double)N[m[c]].bmin[a]) : (double)N[m[c]].bmin[a];
-					hi[a] = c ? std::max(hi[a], (double)N[m[c]].bmax[a]) : (double)N[m[c]].bmax[a];
-				}
-			uint32_t expo = 0, q[6] = {0, 0, 0, 0, 0, 0};  // lo.x hi.x lo.y hi.y lo.z hi.z, one byte per child
-			for (int a = 0; a < 3; ++a) {
-				// smallest power-of-two step with 254 steps >= extent (one step of slack for the rounding of
-				// the double arithmetic below), as a biased float exponent in 1..254
-				int e = 1;
-				while (e < 254 && 254.0 * std::ldexp(1.0, e - 127) < hi[a] - lo[a]) ++e;
-				const double step = std::ldexp(1.0, e - 127);
-				if (254.0 * step < hi[a] - lo[a]) wideOk = false;
-				expo |= (uint32_t)e << (8 * a);
-				for (int c = 0; c < k; ++c) {
-					const double cmin = N[m[c]].bmin[a], cmax = N[m[c]].bmax[a];
-					uint32_t l = (uint32_t)std::min(255.0, std::max(0.0, std::floor((cmin - lo[a]) / step)));
-					uint32_t u = (uint32_t)std::min(255.0, std::max(0.0, std::ceil((cmax - lo[a]) / step)));
-					// A rounded double sum that compares strictly beyond a float proves the exact sum is at or
-					// beyond it; move outwards until that holds (the ends of the range hold by construction).
-					while (l > 0 && !(lo[a] + l * step < cmin)) --l;
-					while (u < 255 && !(lo[a] + u * step > cmax)) ++u;
-					q[a * 2 + 0] |= l << (8 * c);
-					q[a * 2 + 1] |= u << (8 * c);
-				}
-			}
-			int code[4] = {0, 0, 0, 0}, deepest = 0;
-			for (int c = 0; c < k; ++c) {
-				if (N[m[c]].tri >= 0) code[c] = ~rankOf[N[m[c]].tri];
-				else {
-					code[c] = wideOf[m[c]];
-					deepest = std::max(deepest, need[wideOf[m[c]]]);
-				}
-			}
-			// all children pushed, one popped and expanded while the others wait
-			need[h] = std::max(k, k - 1 + deepest);
-			auto bits = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
-			wide[h * 4 + 0] = make_float4((float)lo[0], (float)lo[1], (float)lo[2], bits(expo));
-			wide[h * 4 + 1] = make_float4(bits(q[0]), bits(q[1]), bits(q[2]), bits(q[3]));
-			wide[h * 4 + 2] = make_float4(bits(q[4]), bits(q[5]), bits((uint32_t)code[0]), bits((uint32_t)code[1]));
-			wide[h * 4 + 3] = make_float4(bits((uint32_t)code[2]), bits((uint32_t)code[3]), 0.0f, 0.0f);
+			built = rtxwide::collapse_wide(ref, rankOf, wide, wideStackNeed) && wideStackNeed <= WIDE_STACK_MAX;
+			treeKind = "reference";
 		}
-		wideStackNeed = std::max(1, need[0]);
-		if (wideStackNeed > WIDE_STACK_MAX) wideOk = false;
+		wideOk = built;
 	}
 
 	if (std::getenv("RTX_TRACE_DEBUG"))
-		std::fprintf(stderr, "[rtx] wide tree: ok %d, %zu nodes, stack need %d (binary: %zu pairs, stack need %d)\n", (int)wideOk,
-					 wide.size() / 4, wideStackNeed, npairs, maxInteriorDepth + 1);
+		std::fprintf(stderr, "[rtx] wide tree (%s): ok %d, %zu nodes, stack need %d (binary: %zu pairs, stack need %d)\n", treeKind,
+					 (int)wideOk, wide.size() / 16, wideStackNeed, npairs, maxInteriorDepth + 1);
 
 	// Triangle records in rank order.
 	std::vector<float4> th((size_t)std::max<uint32_t>(ntri, 1) * 4), ts((size_t)std::max<uint32_t>(ntri, 1) * 6);
@@ -2018,12 +1991,12 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 	HIPCHK(s->dPairs.alloc(pairs.size()));
 	HIPCHK(hipMemcpy(s->dPairs.p, pairs.data(), pairs.size() * sizeof(float4), hipMemcpyHostToDevice));
 	if (wideOk) {
-		HIPCHK(s->dWide.alloc(wide.size()));
-		HIPCHK(hipMemcpy(s->dWide.p, wide.data(), wide.size() * sizeof(float4), hipMemcpyHostToDevice));
+		HIPCHK(s->dWide.alloc(wide.size() / 4));
+		HIPCHK(hipMemcpy(s->dWide.p, wide.data(), wide.size() * sizeof(float), hipMemcpyHostToDevice));
 	}
 	s->wideOk = wideOk;
 	s->wideStackNeed = wideStackNeed;
-	s->numWide = (uint32_t)(wide.size() / 4);
+	s->numWide = (uint32_t)(wide.size() / 16);
 	HIPCHK(s->dTriHit.alloc(th.size()));
 	HIPCHK(hipMemcpy(s->dTriHit.p, th.data(), th.size() * sizeof(float4), hipMemcpyHostToDevice));
 	HIPCHK(s->dTriShade.alloc(ts.size()));

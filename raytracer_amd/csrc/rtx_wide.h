@@ -1,0 +1,324 @@
+// Host-side construction of the 4-wide, 8-bit quantised tree that k_trace_wide walks.
+//
+// For a ray whose reciprocals are finite, the candidate list of the reference's BVH::hit
+// (src/BVH.cpp:170-189) is exactly the set of triangles whose own bounding box passes AABB::hit, in the
+// reference's leaf order.  The order is carried by each triangle's rank, the membership by the exact
+// leaf test in the kernel; the interior of the tree only prunes.  The pruning tree therefore need not be
+// the reference's (an object-median split, src/BVH.cpp:93-111): it is built here with a binned
+// surface-area heuristic, which visits far fewer nodes per ray, and collapsed four wide.
+#pragma once
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace rtxwide {
+
+struct BinNode {
+	float bmin[3], bmax[3];
+	int left = -1, right = -1;  // children (index into the node array) or -1
+	int tri = -1;               // >= 0: leaf of that triangle
+};
+
+struct Prim {
+	float bmin[3], bmax[3], c[3];
+	int tri;
+};
+
+inline double half_area(const float* mn, const float* mx) {
+	double dx = (double)mx[0] - mn[0], dy = (double)mx[1] - mn[1], dz = (double)mx[2] - mn[2];
+	return dx * dy + dy * dz + dz * dx;
+}
+
+inline void grow(float* mn, float* mx, const float* omn, const float* omx) {
+	for (int a = 0; a < 3; ++a) {
+		mn[a] = std::min(mn[a], omn[a]);
+		mx[a] = std::max(mx[a], omx[a]);
+	}
+}
+
+inline void reset(float* mn, float* mx) {
+	for (int a = 0; a < 3; ++a) {
+		mn[a] = FLT_MAX;
+		mx[a] = -FLT_MAX;
+	}
+}
+
+// Binned SAH split of prims[start,end) (16 bins per axis, one triangle per leaf).  Returns the split
+// position; both sides are non-empty.
+inline int sah_split(std::vector<Prim>& prims, int start, int end) {
+	constexpr int BINS = 16;
+	float cmin[3], cmax[3];
+	reset(cmin, cmax);
+	for (int i = start; i < end; ++i)
+		for (int a = 0; a < 3; ++a) {
+			cmin[a] = std::min(cmin[a], prims[i].c[a]);
+			cmax[a] = std::max(cmax[a], prims[i].c[a]);
+		}
+	double bestCost = DBL_MAX;
+	int bestAxis = -1, bestPlane = 0;
+	for (int axis = 0; axis < 3; ++axis) {
+		const float ext = cmax[axis] - cmin[axis];
+		if (!(ext > 0.0f)) continue;
+		const float scale = (float)BINS / ext;
+		int cnt[BINS] = {0};
+		float bmn[BINS][3], bmx[BINS][3];
+		for (int b = 0; b < BINS; ++b) reset(bmn[b], bmx[b]);
+		for (int i = start; i < end; ++i) {
+			int b = std::min(BINS - 1, std::max(0, (int)((prims[i].c[axis] - cmin[axis]) * scale)));
+			cnt[b]++;
+			grow(bmn[b], bmx[b], prims[i].bmin, prims[i].bmax);
+		}
+		double rightArea[BINS];
+		int rightCnt[BINS];
+		float rmn[3], rmx[3];
+		reset(rmn, rmx);
+		int rc = 0;
+		for (int b = BINS - 1; b > 0; --b) {
+			if (cnt[b]) grow(rmn, rmx, bmn[b], bmx[b]);
+			rc += cnt[b];
+			rightArea[b] = rc ? half_area(rmn, rmx) : 0.0;
+			rightCnt[b] = rc;
+		}
+		float lmn[3], lmx[3];
+		reset(lmn, lmx);
+		int lc = 0;
+		for (int b = 0; b < BINS - 1; ++b) {  // plane b: bins 0..b on the left
+			if (cnt[b]) grow(lmn, lmx, bmn[b], bmx[b]);
+			lc += cnt[b];
+			if (lc == 0 || rightCnt[b + 1] == 0) continue;
+			double cost = half_area(lmn, lmx) * lc + rightArea[b + 1] * rightCnt[b + 1];
+			if (cost < bestCost) {
+				bestCost = cost;
+				bestAxis = axis;
+				bestPlane = b;
+			}
+		}
+	}
+	if (bestAxis < 0) return (start + end) / 2;  // all centroids coincide
+	const float scale = (float)BINS / (cmax[bestAxis] - cmin[bestAxis]);
+	const float base = cmin[bestAxis];
+	auto mid = std::partition(prims.begin() + start, prims.begin() + end, [&](const Prim& p) {
+		int b = std::min(BINS - 1, std::max(0, (int)((p.c[bestAxis] - base) * scale)));
+		return b <= bestPlane;
+	});
+	int split = (int)(mid - prims.begin());
+	if (split == start || split == end) split = (start + end) / 2;  // cannot happen; keeps the recursion finite
+	return split;
+}
+
+struct Range {
+	int node, start, end;
+};
+
+// Subtree under pool[first.node]; ranges of at most `handoff` primitives are deferred (0: none).
+inline void build_range(std::vector<BinNode>& pool, std::vector<Prim>& prims, Range first, int handoff,
+						std::vector<Range>* deferred) {
+	std::vector<Range> st;
+	st.push_back(first);
+	while (!st.empty()) {
+		Range w = st.back();
+		st.pop_back();
+		const int count = w.end - w.start;
+		if (count == 1) {
+			pool[w.node].tri = prims[w.start].tri;
+			continue;
+		}
+		if (deferred && count <= handoff && w.node != first.node) {
+			deferred->push_back(w);
+			continue;
+		}
+		const int split = sah_split(prims, w.start, w.end);
+		BinNode l, r;
+		reset(l.bmin, l.bmax);
+		for (int i = w.start; i < split; ++i) grow(l.bmin, l.bmax, prims[i].bmin, prims[i].bmax);
+		reset(r.bmin, r.bmax);
+		for (int i = split; i < w.end; ++i) grow(r.bmin, r.bmax, prims[i].bmin, prims[i].bmax);
+		pool.push_back(l);
+		pool.push_back(r);
+		const int li = (int)pool.size() - 2;
+		pool[w.node].left = li;
+		pool[w.node].right = li + 1;
+		st.push_back(Range{li, w.start, split});
+		st.push_back(Range{li + 1, split, w.end});
+	}
+}
+
+// Binary SAH tree over triangle boxes (box[i*6 .. i*6+5] = min xyz, max xyz).  Node 0 is the root.
+inline void build_sah(const std::vector<float>& box, int ntri, std::vector<BinNode>& pool, int nthreads) {
+	std::vector<Prim> prims((size_t)ntri);
+	BinNode root;
+	reset(root.bmin, root.bmax);
+	for (int i = 0; i < ntri; ++i) {
+		Prim& p = prims[i];
+		for (int a = 0; a < 3; ++a) {
+			p.bmin[a] = box[(size_t)i * 6 + a];
+			p.bmax[a] = box[(size_t)i * 6 + 3 + a];
+			p.c[a] = 0.5f * p.bmin[a] + 0.5f * p.bmax[a];
+		}
+		p.tri = i;
+		grow(root.bmin, root.bmax, p.bmin, p.bmax);
+	}
+	pool.clear();
+	pool.reserve(2 * (size_t)ntri + 2);
+	pool.push_back(root);
+	if (ntri == 0) return;
+	const bool parallel = nthreads > 1 && ntri >= 16384;
+	std::vector<Range> deferred;
+	const int handoff = parallel ? std::max(2048, ntri / (nthreads * 8)) : 0;
+	build_range(pool, prims, Range{0, 0, ntri}, handoff, parallel ? &deferred : nullptr);
+	if (!parallel || deferred.empty()) return;
+	struct Job {
+		Range r;
+		std::vector<BinNode> local;  // local[0] mirrors the subtree's root
+	};
+	std::vector<Job> jobs(deferred.size());
+	for (size_t k = 0; k < deferred.size(); ++k) jobs[k].r = deferred[k];
+	std::atomic<size_t> next(0);
+	auto worker = [&] {
+		for (;;) {
+			size_t k = next.fetch_add(1);
+			if (k >= jobs.size()) break;
+			Job& jb = jobs[k];
+			jb.local.reserve(2 * (size_t)(jb.r.end - jb.r.start) + 2);
+			jb.local.push_back(pool[jb.r.node]);
+			build_range(jb.local, prims, Range{0, jb.r.start, jb.r.end}, 0, nullptr);  // disjoint slices of prims
+		}
+	};
+	std::vector<std::thread> th;
+	for (int t = 0; t < nthreads; ++t) th.emplace_back(worker);
+	for (auto& t : th) t.join();
+	for (Job& jb : jobs) {
+		const int base = (int)pool.size() - 1;  // local index i > 0 -> pool index base + i
+		auto fix = [&](int c) { return c > 0 ? base + c : c; };
+		pool[jb.r.node].left = fix(jb.local[0].left);
+		pool[jb.r.node].right = fix(jb.local[0].right);
+		pool[jb.r.node].tri = jb.local[0].tri;
+		for (size_t i = 1; i < jb.local.size(); ++i) {
+			BinNode b = jb.local[i];
+			b.left = fix(b.left);
+			b.right = fix(b.right);
+			pool.push_back(b);
+		}
+	}
+}
+
+// Collapses a binary tree four wide and quantises it.  out: 16 floats per wide node,
+//   px py pz (ex | ey << 8 | ez << 16: biased exponents of the quantisation steps)
+//   lo.x[4] hi.x[4] lo.y[4] hi.y[4]      one byte per child
+//   lo.z[4] hi.z[4] code0 code1
+//   code2 code3 - -                        code > 0 wide node, < 0 ~rank of a triangle, 0 absent
+// A node's children are found by opening, largest surface first, the interior children of the binary
+// node until there are four.  stackNeed: entries a traversal may have waiting when it takes the nearest
+// child directly and stacks the others.  Returns false when a box cannot be represented.
+inline bool collapse_wide(const std::vector<BinNode>& N, const std::vector<int>& rankOf, std::vector<float>& out, int& stackNeed) {
+	auto interior = [&](int i) { return N[i].tri < 0 && (N[i].left >= 0 || N[i].right >= 0); };
+	auto usable = [&](int i) { return i >= 0 && (N[i].tri >= 0 || interior(i)); };
+	auto members = [&](int x, int m[4]) {
+		int k = 0;
+		if (N[x].tri >= 0) {  // a tree that is a single leaf
+			m[k++] = x;
+			return k;
+		}
+		for (int ch : {N[x].left, N[x].right})
+			if (usable(ch)) m[k++] = ch;
+		while (k < 4) {
+			int pick = -1;
+			double area = -1.0;
+			for (int c = 0; c < k; ++c)
+				if (interior(m[c])) {
+					int kids = (int)usable(N[m[c]].left) + (int)usable(N[m[c]].right);
+					if (k - 1 + kids > 4) continue;
+					double a = half_area(N[m[c]].bmin, N[m[c]].bmax);
+					if (a > area) {
+						area = a;
+						pick = c;
+					}
+				}
+			if (pick < 0) break;
+			const int open = m[pick];
+			m[pick] = m[k - 1];
+			--k;
+			for (int ch : {N[open].left, N[open].right})
+				if (usable(ch)) m[k++] = ch;
+		}
+		return k;
+	};
+	std::vector<int> wideOf(N.size(), 0), worder;
+	worder.push_back(0);
+	for (size_t h = 0; h < worder.size(); ++h) {
+		int m[4];
+		const int k = members(worder[h], m);
+		for (int c = 0; c < k; ++c)
+			if (N[m[c]].tri < 0) {
+				wideOf[m[c]] = (int)worder.size();
+				worder.push_back(m[c]);
+			}
+	}
+	out.assign(worder.size() * 16, 0.0f);
+	std::vector<int> need(worder.size(), 0);
+	bool ok = true;
+	auto bits = [](uint32_t u) {
+		float f;
+		std::memcpy(&f, &u, 4);
+		return f;
+	};
+	for (size_t h = worder.size(); h-- > 0;) {
+		int m[4];
+		const int k = members(worder[h], m);
+		double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+		for (int c = 0; c < k; ++c)
+			for (int a = 0; a < 3; ++a) {
+				lo[a] = c ? std::min(lo[a], (double)N[m[c]].bmin[a]) : (double)N[m[c]].bmin[a];
+				hi[a] = c ? std::max(hi[a], (double)N[m[c]].bmax[a]) : (double)N[m[c]].bmax[a];
+			}
+		uint32_t expo = 0, q[6] = {0, 0, 0, 0, 0, 0};  // lo.x hi.x lo.y hi.y lo.z hi.z
+		for (int a = 0; a < 3; ++a) {
+			// smallest power-of-two step with 254 steps >= extent (one step of slack for the rounding of
+			// the double arithmetic below), as a biased float exponent in 1..254
+			int e = 1;
+			while (e < 254 && 254.0 * std::ldexp(1.0, e - 127) < hi[a] - lo[a]) ++e;
+			const double step = std::ldexp(1.0, e - 127);
+			if (254.0 * step < hi[a] - lo[a]) ok = false;
+			expo |= (uint32_t)e << (8 * a);
+			for (int c = 0; c < 4; ++c) {
+				if (c >= k) {  // absent child: an empty interval, which no ray enters
+					q[a * 2 + 0] |= 255u << (8 * c);
+					continue;
+				}
+				const double cmin = N[m[c]].bmin[a], cmax = N[m[c]].bmax[a];
+				uint32_t l = (uint32_t)std::min(255.0, std::max(0.0, std::floor((cmin - lo[a]) / step)));
+				uint32_t u = (uint32_t)std::min(255.0, std::max(0.0, std::ceil((cmax - lo[a]) / step)));
+				// A rounded double sum that compares strictly beyond a float proves the exact sum is at or
+				// beyond it; move outwards until that holds (the ends of the range hold by construction).
+				while (l > 0 && !(lo[a] + l * step < cmin)) --l;
+				while (u < 255 && !(lo[a] + u * step > cmax)) ++u;
+				q[a * 2 + 0] |= l << (8 * c);
+				q[a * 2 + 1] |= u << (8 * c);
+			}
+		}
+		int code[4] = {0, 0, 0, 0}, deepest = 0;
+		for (int c = 0; c < k; ++c) {
+			if (N[m[c]].tri >= 0) code[c] = ~rankOf[N[m[c]].tri];
+			else {
+				code[c] = wideOf[m[c]];
+				deepest = std::max(deepest, need[wideOf[m[c]]]);
+			}
+		}
+		need[h] = std::max(0, k - 1) + deepest;
+		float* w = &out[h * 16];
+		w[0] = (float)lo[0]; w[1] = (float)lo[1]; w[2] = (float)lo[2]; w[3] = bits(expo);
+		w[4] = bits(q[0]); w[5] = bits(q[1]); w[6] = bits(q[2]); w[7] = bits(q[3]);
+		w[8] = bits(q[4]); w[9] = bits(q[5]); w[10] = bits((uint32_t)code[0]); w[11] = bits((uint32_t)code[1]);
+		w[12] = bits((uint32_t)code[2]); w[13] = bits((uint32_t)code[3]);
+	}
+	stackNeed = std::max(1, need[0]);
+	return ok;
+}
+
+}  // namespace rtxwide
