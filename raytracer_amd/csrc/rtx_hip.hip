@@ -546,7 +546,6 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 //                      lo.z[4] hi.z[4] code0 code1
 //                      code2 code3 - -                         code > 0 node, < 0 ~rank, 0 absent
 constexpr float WIDE_MAX_INV = 1.2676506e30f;  // 2^100
-constexpr int WIDE_STACK_MAX = 52;             // binary depth <= 32 => wide depth <= 17 => 3 * 17 + 1 entries
 
 __device__ __forceinline__ float ubyte_f(unsigned v, int k) { return (float)((v >> (8 * k)) & 0xFFu); }
 
@@ -563,6 +562,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_wide(DevScene sc, const
 	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
 	unsigned boxTests = 0, triTests = 0, nodeVisits = 0, leafFetches = 0;
 	unsigned walkIters = 0, leafIters = 0, walkLanes = 0, leafLanes = 0;  // wave-level, kept by lane 0
+	unsigned overflows = 0;
 	int cnext = 0, cend = 0;
 	bool more = true;
 	int j = -1, cur = -1, sp = 0;
@@ -739,7 +739,14 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_wide(DevScene sc, const
 				RTX_CSWAP(1, 2)
 #undef RTX_CSWAP
 				// the nearest is looked at next, the others wait with the farthest at the bottom
-				// (the host picks STACK for the tree, so the slots exist)
+				if (sp + nh - 1 > STACK) {
+					// no room: the ray starts over in the binary-tree kernel, whose stack covers its whole tree
+					unsafeList[atomicAdd(unsafeCount, 1u)] = j;
+					if (STATS) overflows++;
+					busy = false;
+					sp = 0;
+					nh = 0;
+				}
 				if (nh > 3) stk[sp][tid] = cd[3];
 				if (nh > 2) stk[sp + nh - 3][tid] = cd[2];
 				if (nh > 1) stk[sp + nh - 2][tid] = cd[1];
@@ -785,6 +792,10 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_wide(DevScene sc, const
 			atomicAdd(&stats[3], (unsigned long long)walkLanes);
 			atomicAdd(&stats[6], (unsigned long long)leafIters);
 			atomicAdd(&stats[7], (unsigned long long)leafLanes);
+		}
+		for (int off = 32; off > 0; off >>= 1) overflows += __shfl_down(overflows, off, 64);
+		if (lane == 0) {
+			atomicAdd(&stats[8], (unsigned long long)overflows);
 		}
 	}
 }
@@ -1233,6 +1244,7 @@ struct rtx_scene {
 	int treeDepth = 0;
 	int stackNeed = 32;  // deepest interior node: the traversal pushes at most once per interior level
 	int wideStackNeed = 52;  // wide traversal: entries waiting when every child of every node on a path is hit
+	int wideStackCap = 24;   // RTX_WIDE_STACK: 16, 24 or 32
 	bool wideOk = false;     // the tree satisfies what k_trace_wide relies on
 	bool forceBinary = false;  // RTX_TRACE_BINARY=1: binary-tree kernel only (for comparisons)
 	uint32_t numWide = 0;
@@ -1369,9 +1381,9 @@ int ensure_ready(rtx_scene* s, bool needCamera) {
 	}
 	if (!s->dCounts.p) {
 		HIPCHK(s->dCounts.alloc((MAX_DEPTH + 2) * CNT_STRIDE));
-		HIPCHK(s->dStats.alloc(8));
+		HIPCHK(s->dStats.alloc(12));
 		HIPCHK(hipHostMalloc((void**)&s->hCounts, (MAX_DEPTH + 2) * CNT_STRIDE * sizeof(unsigned), hipHostMallocDefault));
-		HIPCHK(hipHostMalloc((void**)&s->hStats, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+		HIPCHK(hipHostMalloc((void**)&s->hStats, 12 * sizeof(unsigned long long), hipHostMallocDefault));
 	}
 	return RTX_OK;
 }
@@ -1472,23 +1484,22 @@ int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float
 				  int* unsafeList, unsigned* unsafeCount) {
 	const int wanted = (n + TRACE_THREADS - 1) / TRACE_THREADS;
 	dim3 grid(std::min(wanted, s->numCUs * s->traceBlocksPerCU)), block(TRACE_THREADS);
-	const int need = s->wideStackNeed;
+	// The stack is no deeper than wideStackCap entries however deep the tree: a ray that would need more
+	// moves to the binary-tree kernel.  Fewer entries, more resident waves.
+	const int need = std::min(s->wideStackNeed, s->wideStackCap);
 	const bool st = s->instrumented;
 	unsigned long long* stats = s->dStats.p;
 #define RTX_LAUNCH(STK, ST)                                                                                              \
 	hipLaunchKernelGGL((k_trace_wide<STK, ANYHIT, ST>), grid, block, 0, s->stream, d, ro, rd, hits, n, stats, work,      \
 					   unsafeList, unsafeCount, s->traceRefill, s->traceChunk, s->traceTriBatch)
-	if (need <= 24) {
+	if (need <= 16) {
+		if (st) RTX_LAUNCH(16, true); else RTX_LAUNCH(16, false);
+	}
+	else if (need <= 24) {
 		if (st) RTX_LAUNCH(24, true); else RTX_LAUNCH(24, false);
 	}
-	else if (need <= 32) {
-		if (st) RTX_LAUNCH(32, true); else RTX_LAUNCH(32, false);
-	}
-	else if (need <= 40) {
-		if (st) RTX_LAUNCH(40, true); else RTX_LAUNCH(40, false);
-	}
 	else {
-		if (st) RTX_LAUNCH(WIDE_STACK_MAX, true); else RTX_LAUNCH(WIDE_STACK_MAX, false);
+		if (st) RTX_LAUNCH(32, true); else RTX_LAUNCH(32, false);
 	}
 #undef RTX_LAUNCH
 	HIPCHK(hipGetLastError());
@@ -1679,13 +1690,13 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 
 int finish_stats(rtx_scene* s) {
 	if (s->instrumented) {
-		HIPCHK(hipMemcpy(s->hStats, s->dStats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(s->hStats, s->dStats.p, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 		s->stats.node_tests = s->hStats[0];
 		s->stats.tri_tests = s->hStats[1];
 		if (std::getenv("RTX_TRACE_DEBUG"))
-			std::fprintf(stderr, "[rtx] wide: walk iterations %llu with %.1f lanes, leaf phases %llu with %.1f lanes\n", s->hStats[2],
+			std::fprintf(stderr, "[rtx] wide: walk iterations %llu with %.1f lanes, leaf phases %llu with %.1f lanes, %llu stack overflows\n", s->hStats[2],
 						 (double)s->hStats[3] / (double)std::max(1ull, s->hStats[2]), s->hStats[6],
-						 (double)s->hStats[7] / (double)std::max(1ull, s->hStats[6]));
+						 (double)s->hStats[7] / (double)std::max(1ull, s->hStats[6]), s->hStats[8]);
 		s->stats.wide_visits = s->hStats[4];
 		s->stats.leaf_fetches = s->hStats[5];
 	}
@@ -1694,7 +1705,7 @@ int finish_stats(rtx_scene* s) {
 
 int begin_call(rtx_scene* s) {
 	std::memset(&s->stats, 0, sizeof(s->stats));
-	if (s->instrumented) HIPCHK(hipMemsetAsync(s->dStats.p, 0, 8 * sizeof(unsigned long long), s->stream));
+	if (s->instrumented) HIPCHK(hipMemsetAsync(s->dStats.p, 0, 12 * sizeof(unsigned long long), s->stream));
 	return RTX_OK;
 }
 
@@ -1727,6 +1738,7 @@ RTX_API int rtx_scene_create(rtx_scene** out, int device) {
 	if (const char* e = std::getenv("RTX_TRACE_TRI_BATCH")) s->traceTriBatch = std::max(1, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_TRACE_BLOCKS_PER_CU")) s->traceBlocksPerCU = std::max(1, std::atoi(e));
 	if (const char* e = std::getenv("RTX_TRACE_BINARY")) s->forceBinary = std::atoi(e) != 0;
+	if (const char* e = std::getenv("RTX_WIDE_STACK")) s->wideStackCap = std::max(16, std::min(32, std::atoi(e)));
 	std::memset(&s->stats, 0, sizeof(s->stats));
 	*out = s;
 	return RTX_OK;
@@ -1933,7 +1945,7 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 			std::vector<rtxwide::BinNode> own;
 			const int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 			rtxwide::build_sah(box, (int)ntri, own, threads);
-			built = rtxwide::collapse_wide(own, rankOf, wide, wideStackNeed) && wideStackNeed <= WIDE_STACK_MAX;
+			built = rtxwide::collapse_wide(own, rankOf, wide, wideStackNeed);
 			treeKind = "surface-area";
 		}
 		if (!built) {
@@ -1945,7 +1957,7 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 				ref[i].right = N[i].right > 0 ? N[i].right : -1;
 				ref[i].tri = N[i].tri >= 0 ? N[i].tri : -1;
 			}
-			built = rtxwide::collapse_wide(ref, rankOf, wide, wideStackNeed) && wideStackNeed <= WIDE_STACK_MAX;
+			built = rtxwide::collapse_wide(ref, rankOf, wide, wideStackNeed);
 			treeKind = "reference";
 		}
 		wideOk = built;
