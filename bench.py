@@ -73,6 +73,17 @@ def cpu_baseline(sc, nodes, seconds_target=15.0):
     }
 
 
+def measured_traffic():
+    """HBM bytes per traversal launch from the rocprofv3 PMC passes (FETCH_SIZE doubled as gfx950 needs, plus
+    WRITE_SIZE), as recorded by profiles/summarize.py into raytracer_amd/measured.json; None when absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "raytracer_amd", "measured.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("k_trace_wide_hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,7 +190,7 @@ def main():
 
     # node/triangle test counts of this rank's share, from one instrumented frame outside the timed region
     # (frame `frame - 1` again: identical rays); they feed the algorithmic-bytes figure of the trace kernel.
-    n_node = n_tri = None
+    n_node = n_tri = n_wide = n_leaf = None
     if not args.no_instrument and args.balance == "static":
         rt.set_instrumented(True)
         rt.render(frame - 1, 1)
@@ -187,6 +198,8 @@ def main():
         rt.set_instrumented(False)
         n_node = st["node_tests"] / max(st["rays"], 1)
         n_tri = st["tri_tests"] / max(st["rays"], 1)
+        n_wide = st["wide_visits"] / max(st["rays"], 1)
+        n_leaf = st["leaf_fetches"] / max(st["rays"], 1)
 
     if rank == 0:
         samples = sc.width * sc.height * 4 * args.steps
@@ -202,15 +215,19 @@ def main():
             "gpu_kernel_ms_per_step": {"trace": round(trace_ms_sum / args.steps / world, 3), "shade_gather_accumulate": round(shade_ms_sum / args.steps / world, 3)},
         }
         if n_node is not None:
-            # algorithmic bytes the traversal kernel must move per ray: 32 B per box test (half of a 64-B
-            # pair record), 64 B per triangle test, 32 B ray in, 16 B hit out
-            bytes_per_ray = 32.0 * n_node + 64.0 * n_tri + 48.0
+            # algorithmic bytes the traversal kernel must move per ray: one 64-B record per node of the 4-wide
+            # tree it visits, one 64-B record per triangle whose quantised box it enters, 32 B ray in, 16 B hit out
+            bytes_per_ray = 64.0 * n_wide + 64.0 * n_leaf + 48.0
             achieved = bytes_per_ray * rays_total / (trace_ms_sum / world * 1e-3) / 1e9 if trace_ms_sum > 0 else 0.0
-            out["roofline"] = {"bound": "hbm", "kernel": "k_trace", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            out["roofline"] = {"bound": "hbm", "kernel": "k_trace_wide", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),
+                               "node_visits_per_ray": round(n_wide, 2), "leaf_fetches_per_ray": round(n_leaf, 3),
                                "box_tests_per_ray": round(n_node, 2), "triangle_tests_per_ray": round(n_tri, 3),
                                "bytes_per_ray": round(bytes_per_ray, 1),
-                               "avg_launch_ms": round(trace_ms_sum / max(counters["launches"] * world, 1), 4)}
+                               "avg_launch_ms": round(trace_ms_sum / max(counters["launches"] * world, 1), 4),
+                               "note": "the records are re-read from L2/Infinity Cache (tree + triangles = 25 MB), so algorithmic "
+                                       "bytes/s can approach the HBM figure without HBM traffic; the kernel's measured limiter is "
+                                       "vector-ALU issue (SQ_ACTIVE_INST_VALU ~ 98 % of SIMD cycles), see profiles/"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, nodes)
         print(json.dumps(out))
