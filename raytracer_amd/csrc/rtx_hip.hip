@@ -532,25 +532,32 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 // inside its parent's box exactly (both are min/max over vertex sets), so if the slab predicate
 // (src/BVH.cpp:14-41) passes for a leaf's own box it passes for every ancestor: for such rays the
 // candidate list of BVH::hit is exactly "the triangles whose own box passes".  The interior boxes only
-// prune, and any conservative bound may stand in for them.  This kernel therefore walks a 4-wide
-// collapse of the reference's tree (a node holds the up to four grandchildren of a binary node) whose
-// child boxes are quantised to 8 bits per coordinate inside the node's box, rounded outwards, and tested
-// inflated by the same position-space slack as the culling bounds; 64 bytes serve two levels of the
-// binary tree instead of up to 192.  Leaves are tested with the exact predicate on their exact box
-// (recomputed from the vertices) and the exact Triangle::hit, and ties go to the reference's
-// candidate order, so the result equals the reference's.  Rays with a zero or sub-2^-100 direction
-// component are set aside in a list for the binary-tree kernel above, which evaluates every ancestor.
+// prune, and any conservative bound may stand in for them.  This kernel therefore walks a 4-wide tree of
+// its own (rtx_wide.h) whose child boxes are quantised to 8 bits per coordinate inside the node's box,
+// rounded outwards, and tested inflated by the same position-space slack as the culling bounds.  Leaves
+// are tested with the exact predicate on their exact box (recomputed from the vertices) and the exact
+// Triangle::hit, and ties go to the reference's candidate order, so the result equals the reference's.
 //
-// Node, 4 x 16 bytes:  px py pz (ex|ey<<8|ez<<16: biased exponents of the quantisation step)
+// A ray parallel to an axis (1/d = +-inf there) is walked here too.  On that axis the reference computes
+// +-inf, or NaN where the origin lies on a box plane.  Its folds over lanes 1 and 2 (y, z) skip a NaN, which
+// is the same as the unconstrained (-inf, +inf) a parent's wider slab gives, so the argument above still
+// holds.  A NaN in lane 0 (x) makes the reference accept the box whatever the other axes say, which a
+// parent need not do: a ray that meets that case at a leaf is set aside in a list for the binary-tree kernel
+// above, which evaluates every ancestor as the reference does; so are rays with a finite reciprocal beyond
+// 2^100 (whose products overflow) and rays that need more stack than this kernel has.  The quantised
+// tests are homogeneous in 1/d; they use +-2^100 in place of +-inf and so prune a parallel ray by
+// "origin inside the slab, give or take the slack".
+//
+// Node, 4 x 16 bytes:  px py pz sx                          (origin; sx, sy, sz: quantisation steps, powers of two)
 //                      lo.x[4] hi.x[4] lo.y[4] hi.y[4]      (one byte per child)
 //                      lo.z[4] hi.z[4] code0 code1
-//                      code2 code3 - -                         code > 0 node, < 0 ~rank, 0 absent
+//                      code2 code3 sy sz                       code > 0 node, < 0 ~rank, 0 absent
 constexpr float WIDE_MAX_INV = 1.2676506e30f;  // 2^100
 
 __device__ __forceinline__ float ubyte_f(unsigned v, int k) { return (float)((v >> (8 * k)) & 0xFFu); }
 
 template <int STACK, bool ANYHIT, bool STATS>
-__global__ __launch_bounds__(TRACE_THREADS) void k_trace_wide(DevScene sc, const float4* __restrict__ rayO,
+__global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_trace_wide(DevScene sc, const float4* __restrict__ rayO,
 															   const float4* __restrict__ rayD, float4* __restrict__ hits,
 															   int n, unsigned long long* __restrict__ stats,
 															   unsigned* __restrict__ work, int* __restrict__ unsafeList,
@@ -570,13 +577,14 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_wide(DevScene sc, const
 	r.ox = r.oy = r.oz = r.ix = r.iy = r.iz = r.mx = r.my = r.mz = 0.0f;
 	r.nx = r.ny = r.nz = false;
 	float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+	float wix = 0.0f, wiy = 0.0f, wiz = 0.0f;  // 1/d as the interior tests use it: +-inf replaced by +-2^100
 	HitState best;
 	best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
 	bool found = false, busy = false;
 	int pend0 = -1, pend1 = -1;
 
 	for (;;) {
-		const unsigned long long idle = __ballot(!busy);
+		const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
 		const int nidle = __popcll(idle);
 		if (more && nidle >= refill) {
 			if (cnext >= cend) {
@@ -609,7 +617,9 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_wide(DevScene sc, const
 						const bool zero = (dx == 0.0f) & (dy == 0.0f) & (dz == 0.0f);
 						const bool finite = (fabsf(dx) <= FLT_MAX) & (fabsf(dy) <= FLT_MAX) & (fabsf(dz) <= FLT_MAX) &
 											(r.ox == r.ox) & (r.oy == r.oy) & (r.oz == r.oz);
-						const bool safe = (fabsf(r.ix) <= WIDE_MAX_INV) & (fabsf(r.iy) <= WIDE_MAX_INV) & (fabsf(r.iz) <= WIDE_MAX_INV);
+						const float aix = fabsf(r.ix), aiy = fabsf(r.iy), aiz = fabsf(r.iz);
+						const bool safe = ((aix <= WIDE_MAX_INV) | (aix > FLT_MAX)) & ((aiy <= WIDE_MAX_INV) | (aiy > FLT_MAX)) &
+										  ((aiz <= WIDE_MAX_INV) | (aiz > FLT_MAX));
 						if (zero | !finite) {
 							// no triangle can accept such a ray (see k_trace)
 							hits[j] = make_float4(__int_as_float(-1), FLT_MAX, 0.0f, 0.0f);
@@ -621,9 +631,14 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_wide(DevScene sc, const
 							r.nx = (__float_as_uint(r.ix) >> 31) != 0;
 							r.ny = (__float_as_uint(r.iy) >> 31) != 0;
 							r.nz = (__float_as_uint(r.iz) >> 31) != 0;
+							// The interior tests are homogeneous in 1/d, so on an axis the ray is parallel to a large
+							// finite reciprocal decides "origin inside the slab, give or take the slack" just as well.
+							wix = aix > FLT_MAX ? copysignf(WIDE_MAX_INV, r.ix) : r.ix;
+							wiy = aiy > FLT_MAX ? copysignf(WIDE_MAX_INV, r.iy) : r.iy;
+							wiz = aiz > FLT_MAX ? copysignf(WIDE_MAX_INV, r.iz) : r.iz;
 							float scale = fmaxf(fmaxf(sc.sceneAbsMax, fabsf(r.ox)), fmaxf(fabsf(r.oy), fabsf(r.oz)));
 							float eps = scale * 6.103515625e-05f;
-							r.mx = eps * fabsf(r.ix); r.my = eps * fabsf(r.iy); r.mz = eps * fabsf(r.iz);
+							r.mx = eps * fabsf(wix); r.my = eps * fabsf(wiy); r.mz = eps * fabsf(wiz);
 							best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
 							found = false;
 							sp = 0;
@@ -636,56 +651,69 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_wide(DevScene sc, const
 				cnext += take;
 			}
 		}
-		const bool canWalk = busy && pend0 < 0;
-		const unsigned long long mWalk = __ballot(canWalk);
-		const unsigned long long mPark = __ballot(busy && pend0 >= 0);
-		if (mWalk == 0ull && mPark == 0ull) {
+		// A lane walks while it has something to walk and a free leaf slot: a leaf it comes across is kept
+		// for later (two slots) and the walk goes on to what lies behind it.  That is speculative (the leaf
+		// may turn out to cut those nodes off) but keeps lanes out of the waiting room; the result does not
+		// depend on the order of the tests.
+		const bool canWalk = busy && pend1 < 0 && (cur >= 0 || sp > 0);
+		const unsigned long long mWalk = __builtin_amdgcn_ballot_w64(canWalk);
+		const unsigned long long mLeaf = __builtin_amdgcn_ballot_w64(busy && pend0 >= 0);
+		if (mWalk == 0ull && mLeaf == 0ull) {
 			if (!more) break;
 			continue;
 		}
+		const bool leafPhase = __popcll(mLeaf) >= triBatch || mWalk == 0ull;
 		if (STATS) {
-			if (__popcll(mPark) >= triBatch || mWalk == 0ull) {
+			if (leafPhase) {
 				leafIters++;
-				leafLanes += __popcll(mPark);
+				leafLanes += __popcll(mLeaf);
 			}
 			else {
 				walkIters++;
 				walkLanes += __popcll(mWalk);
 			}
 		}
-		if (__popcll(mPark) >= triBatch || mWalk == 0ull) {
-			// leaf phase: exact box of the triangle, exact slab predicate, exact triangle test
-			for (int rep = 0; rep < 2; ++rep) {
-				if (busy && pend0 >= 0) {
-					const float4* T = sc.triHit + (size_t)pend0 * 4;
-					float4 q0 = T[0], q1 = T[1], q2 = T[2];
-					if (STATS) leafFetches++;
-					const float v0x = q0.w, v0y = q1.x, v0z = q1.y, v1x = q1.z, v1y = q1.w, v1z = q2.x, v2x = q2.y, v2y = q2.z, v2z = q2.w;
-					// the reference's predicate on the leaf's own box (src/BVH.cpp:14-41); every value is finite here
-					const float lx = fminf(fminf(v0x, v1x), v2x), hx = fmaxf(fmaxf(v0x, v1x), v2x);
-					const float ly = fminf(fminf(v0y, v1y), v2y), hy = fmaxf(fmaxf(v0y, v1y), v2y);
-					const float lz = fminf(fminf(v0z, v1z), v2z), hz = fmaxf(fmaxf(v0z, v1z), v2z);
-					const float t0x = (lx - r.ox) * r.ix, t1x = (hx - r.ox) * r.ix;
-					const float t0y = (ly - r.oy) * r.iy, t1y = (hy - r.oy) * r.iy;
-					const float t0z = (lz - r.oz) * r.iz, t1z = (hz - r.oz) * r.iz;
-					const float tmin = fmaxf(fmaxf(r.nx ? t1x : t0x, r.ny ? t1y : t0y), r.nz ? t1z : t0z);
-					const float tmax = fminf(fminf(r.nx ? t0x : t1x, r.ny ? t0y : t1y), r.nz ? t0z : t1z);
-					const bool pass = !(tmax < tmin);
-					if (STATS) boxTests++;
-					if (pass) {
-						if (STATS) triTests++;
-						found |= tri_test_vals(q0.x, q0.y, q0.z, v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z, pend0, r.ox, r.oy,
-											   r.oz, dx, dy, dz, best);
-					}
-					pend0 = pend1;
+		if (leafPhase) {
+			// exact box of the triangle, exact slab predicate, exact triangle test; one leaf per lane and pass
+			if (busy && pend0 >= 0) {
+				const float4* T = sc.triHit + (size_t)pend0 * 4;
+				float4 q0 = T[0], q1 = T[1], q2 = T[2];
+				if (STATS) leafFetches++;
+				const float v0x = q0.w, v0y = q1.x, v0z = q1.y, v1x = q1.z, v1y = q1.w, v1z = q2.x, v2x = q2.y, v2y = q2.z, v2z = q2.w;
+				// the reference's predicate on the leaf's own box (src/BVH.cpp:14-41); lane 0 is never NaN here and
+				// fmaxf/fminf skip a NaN in lanes 1 and 2 as the reference's folds do
+				const float lx = fminf(fminf(v0x, v1x), v2x), hx = fmaxf(fmaxf(v0x, v1x), v2x);
+				const float ly = fminf(fminf(v0y, v1y), v2y), hy = fmaxf(fmaxf(v0y, v1y), v2y);
+				const float lz = fminf(fminf(v0z, v1z), v2z), hz = fmaxf(fmaxf(v0z, v1z), v2z);
+				const float t0x = (lx - r.ox) * r.ix, t1x = (hx - r.ox) * r.ix;
+				const float t0y = (ly - r.oy) * r.iy, t1y = (hy - r.oy) * r.iy;
+				const float t0z = (lz - r.oz) * r.iz, t1z = (hz - r.oz) * r.iz;
+				const float tmin = fmaxf(fmaxf(r.nx ? t1x : t0x, r.ny ? t1y : t0y), r.nz ? t1z : t0z);
+				const float tmax = fminf(fminf(r.nx ? t0x : t1x, r.ny ? t0y : t1y), r.nz ? t0z : t1z);
+				const bool pass = !(tmax < tmin);
+				if (STATS) boxTests++;
+				if (t0x != t0x || t1x != t1x) {
+					// The origin lies on an x plane of this box and the ray runs along it: the reference accepts
+					// such a box whatever y and z say (NaN in lane 0), provided it gets there, which only its own
+					// tree can tell.  The ray starts over in the binary-tree kernel.
+					unsafeList[atomicAdd(unsafeCount, 1u)] = j;
+					busy = false;
+					cur = -1;
+					sp = 0;
 					pend1 = -1;
-					if (ANYHIT && found) {
-						pend0 = -1;
-						cur = -1;
-						sp = 0;
-					}
 				}
-				if (__ballot(busy && pend0 >= 0) == 0ull) break;
+				else if (pass) {
+					if (STATS) triTests++;
+					found |= tri_test_vals(q0.x, q0.y, q0.z, v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z, pend0, r.ox, r.oy,
+										   r.oz, dx, dy, dz, best);
+				}
+				pend0 = pend1;
+				pend1 = -1;
+				if (ANYHIT && found) {
+					pend0 = -1;
+					cur = -1;
+					sp = 0;
+				}
 			}
 		}
 		else if (canWalk) {
@@ -694,11 +722,8 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_wide(DevScene sc, const
 				const float4* W = sc.wide + (size_t)cur * 4;
 				float4 w0 = W[0], w1 = W[1], w2 = W[2], w3 = W[3];
 				if (STATS) nodeVisits++;
-				const unsigned ex = __float_as_uint(w0.w);
-				const float Sx = __uint_as_float((ex & 0xFFu) << 23) * r.ix;
-				const float Sy = __uint_as_float(((ex >> 8) & 0xFFu) << 23) * r.iy;
-				const float Sz = __uint_as_float(((ex >> 16) & 0xFFu) << 23) * r.iz;
-				const float Ax = (w0.x - r.ox) * r.ix, Ay = (w0.y - r.oy) * r.iy, Az = (w0.z - r.oz) * r.iz;
+				const float Sx = w0.w * wix, Sy = w3.z * wiy, Sz = w3.w * wiz;
+				const float Ax = (w0.x - r.ox) * wix, Ay = (w0.y - r.oy) * wiy, Az = (w0.z - r.oz) * wiz;
 				const float Anx = Ax - r.mx, Any = Ay - r.my, Anz = Az - r.mz;
 				const float Afx = Ax + r.mx, Afy = Ay + r.my, Afz = Az + r.mz;
 				const unsigned lox = __float_as_uint(w1.x), hix = __float_as_uint(w1.y), loy = __float_as_uint(w1.z),
@@ -746,6 +771,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_wide(DevScene sc, const
 					busy = false;
 					sp = 0;
 					nh = 0;
+					pend0 = -1;
 				}
 				if (nh > 3) stk[sp][tid] = cd[3];
 				if (nh > 2) stk[sp + nh - 3][tid] = cd[2];
@@ -758,17 +784,21 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_wide(DevScene sc, const
 				sp--;
 				item = stk[sp][tid];
 			}
-			if (item > 0) cur = item;
-			else if (item < 0) {
-				pend0 = ~item;
-				if (sp > 0) {
-					const int nextItem = stk[sp - 1][tid];
-					if (nextItem < 0) {
-						pend1 = ~nextItem;
-						sp--;
+			if (item < 0) {
+				// a leaf: keep it and look at what comes after it
+				if (pend0 < 0) pend0 = ~item;
+				else pend1 = ~item;
+				item = 0;
+				if (pend1 < 0 && sp > 0) {
+					sp--;
+					item = stk[sp][tid];
+					if (item < 0) {
+						pend1 = ~item;
+						item = 0;
 					}
 				}
 			}
+			if (item > 0) cur = item;
 		}
 		if (busy && cur < 0 && pend0 < 0 && sp == 0) {
 			int id = found ? (ANYHIT ? 0 : best.rank) : -1;

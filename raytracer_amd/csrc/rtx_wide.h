@@ -209,10 +209,10 @@ inline void build_sah(const std::vector<float>& box, int ntri, std::vector<BinNo
 }
 
 // Collapses a binary tree four wide and quantises it.  out: 16 floats per wide node,
-//   px py pz (ex | ey << 8 | ez << 16: biased exponents of the quantisation steps)
+//   px py pz sx                          origin; sx, sy, sz: quantisation steps (powers of two)
 //   lo.x[4] hi.x[4] lo.y[4] hi.y[4]      one byte per child
 //   lo.z[4] hi.z[4] code0 code1
-//   code2 code3 - -                        code > 0 wide node, < 0 ~rank of a triangle, 0 absent
+//   code2 code3 sy sz                      code > 0 wide node, < 0 ~rank of a triangle, 0 absent
 // A node's children are found by opening, largest surface first, the interior children of the binary
 // node until there are four.  stackNeed: entries a traversal may have waiting when it takes the nearest
 // child directly and stacks the others.  Returns false when a box cannot be represented.
@@ -277,15 +277,16 @@ inline bool collapse_wide(const std::vector<BinNode>& N, const std::vector<int>&
 				lo[a] = c ? std::min(lo[a], (double)N[m[c]].bmin[a]) : (double)N[m[c]].bmin[a];
 				hi[a] = c ? std::max(hi[a], (double)N[m[c]].bmax[a]) : (double)N[m[c]].bmax[a];
 			}
-		uint32_t expo = 0, q[6] = {0, 0, 0, 0, 0, 0};  // lo.x hi.x lo.y hi.y lo.z hi.z
+		uint32_t q[6] = {0, 0, 0, 0, 0, 0};  // lo.x hi.x lo.y hi.y lo.z hi.z
+		float steps[3];
 		for (int a = 0; a < 3; ++a) {
 			// smallest power-of-two step with 254 steps >= extent (one step of slack for the rounding of
-			// the double arithmetic below), as a biased float exponent in 1..254
+			// the double arithmetic below), with a biased float exponent in 1..254
 			int e = 1;
 			while (e < 254 && 254.0 * std::ldexp(1.0, e - 127) < hi[a] - lo[a]) ++e;
 			const double step = std::ldexp(1.0, e - 127);
 			if (254.0 * step < hi[a] - lo[a]) ok = false;
-			expo |= (uint32_t)e << (8 * a);
+			steps[a] = (float)step;
 			for (int c = 0; c < 4; ++c) {
 				if (c >= k) {  // absent child: an empty interval, which no ray enters
 					q[a * 2 + 0] |= 255u << (8 * c);
@@ -312,10 +313,10 @@ inline bool collapse_wide(const std::vector<BinNode>& N, const std::vector<int>&
 		}
 		need[h] = std::max(0, k - 1) + deepest;
 		float* w = &out[h * 16];
-		w[0] = (float)lo[0]; w[1] = (float)lo[1]; w[2] = (float)lo[2]; w[3] = bits(expo);
+		w[0] = (float)lo[0]; w[1] = (float)lo[1]; w[2] = (float)lo[2]; w[3] = steps[0];
 		w[4] = bits(q[0]); w[5] = bits(q[1]); w[6] = bits(q[2]); w[7] = bits(q[3]);
 		w[8] = bits(q[4]); w[9] = bits(q[5]); w[10] = bits((uint32_t)code[0]); w[11] = bits((uint32_t)code[1]);
-		w[12] = bits((uint32_t)code[2]); w[13] = bits((uint32_t)code[3]);
+		w[12] = bits((uint32_t)code[2]); w[13] = bits((uint32_t)code[3]); w[14] = steps[1]; w[15] = steps[2];
 	}
 	stackNeed = std::max(1, need[0]);
 	return ok;

@@ -111,6 +111,14 @@ def test_secondary_like_rays_and_degenerate_rays(libs):
     o[2000:2200, 1] = 0.0               # origins exactly on the floor plane
     d[2200:2400] *= np.float32(1e-7)
     d[2400:2600] *= np.float32(1e7)
+    # axis-parallel rays from origins on round coordinates, where box planes lie: 0 * inf = NaN inside AABB::hit
+    o[2600:3800] = np.round(o[2600:3800] / 5) * 5
+    d[2600:3000, 1] = 0
+    d[3000:3400, 2] = 0
+    d[3400:3600, 0] = 0
+    d[3600:3800, [1, 2]] = 0
+    d[3800:3900, 1] = np.float32(1e-40)  # denormal component: its reciprocal overflows
+    d[3900:4000, 2] = np.float32(-3e-39)
     ids_o, tab_o = O.closest_hits(o, d)
     for mode in (0, 1):
         ids_g, tab_g = rt.trace_rays(o, d, mode)
