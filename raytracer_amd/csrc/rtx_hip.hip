@@ -82,7 +82,8 @@ struct DevScene {
 	const float4* pairs;     // 4 x float4 per child pair: Lmin|codeL, Lmax|-, Rmin|codeR, Rmax|-
 	const float4* wide;      // 4 x float4 per node of the 4-wide quantised collapse of the tree
 	const float4* triHit;    // 4 x float4 per triangle in candidate-rank order: n, v0, v1, v2, index
-	const float4* triShade;  // 6 x float4 per triangle in candidate-rank order
+	const float4* triShade;  // 4 x float4 per triangle in candidate-rank order: n0 r | n1 g | n2 b | rough ior tex flags
+	const float4* triUv;     // 2 x float4 per triangle: uv0 uv1 | uv2 - -   (read for textured hits only)
 	const uint8_t* texels;
 	const int4* texDesc;     // byte offset, width, height
 	const float* cosT;
@@ -892,11 +893,12 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 		else if (level < sc.maxDepth) {
 			// (at level == maxDepth every hit returns zero, src/RayTracer.cpp:170; the any-hit
 			//  traversal reports such hits with rank 0, which is never dereferenced)
-			const float4* T = sc.triShade + (size_t)rank * 6;
-			float4 s0 = T[0], s1 = T[1], s2 = T[2], s3 = T[3], s4 = T[4], s5 = T[5];
+			// one aligned 64-byte record serves every hit; the texture coordinates live apart
+			const float4* T = sc.triShade + (size_t)rank * 4;
+			float4 s0 = T[0], s1 = T[1], s2 = T[2], s3 = T[3];
 			const float t = H.y, alpha = H.z, beta = H.w;
-			const int triFlags = __float_as_int(s5.y);
-			const int texId = __float_as_int(s5.x);
+			const int triFlags = __float_as_int(s3.w);
+			const int texId = __float_as_int(s3.z);
 			hx = O.x + t * dx;
 			hy = O.y + t * dy;
 			hz = O.z + t * dz;
@@ -922,8 +924,8 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 			else {
 				shaded = 1;
 				val = make_float3(s0.w, s1.w, s2.w);  // colour, consumed by k_gather
-				rough = s4.z;
-				ior = s4.w;
+				rough = s3.x;
+				ior = s3.y;
 				if (triFlags & TRI_METAL) {
 					kind = KIND_METAL;
 					nchild = S;
@@ -938,8 +940,9 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 					scalar = fabsf(cosine);
 					if (texId >= 0) {
 						flags |= FLAG_TEX;
-						float u = (alpha * s3.x + beta * s3.z) + g * s4.x;
-						float v = (alpha * s3.y + beta * s3.w) + g * s4.y;
+						const float4 u01 = sc.triUv[(size_t)rank * 2], u2 = sc.triUv[(size_t)rank * 2 + 1];
+						float u = (alpha * u01.x + beta * u01.z) + g * u2.x;
+						float v = (alpha * u01.y + beta * u01.w) + g * u2.y;
 						texel = tex_fetch(sc, texId, u, v);
 						fetches = 1;
 					}
@@ -1274,13 +1277,13 @@ struct rtx_scene {
 	int treeDepth = 0;
 	int stackNeed = 32;  // deepest interior node: the traversal pushes at most once per interior level
 	int wideStackNeed = 52;  // wide traversal: entries waiting when every child of every node on a path is hit
-	int wideStackCap = 24;   // RTX_WIDE_STACK: 16, 24 or 32
+	int wideStackCap = 24;   // RTX_WIDE_STACK: 16 or 24
 	bool wideOk = false;     // the tree satisfies what k_trace_wide relies on
 	bool forceBinary = false;  // RTX_TRACE_BINARY=1: binary-tree kernel only (for comparisons)
 	uint32_t numWide = 0;
 	uint32_t numPairs = 0;
 	// device
-	DevBuf<float4> dPairs, dWide, dTriHit, dTriShade;
+	DevBuf<float4> dPairs, dWide, dTriHit, dTriShade, dTriUv;
 	DevBuf<uint8_t> dTexels;
 	DevBuf<int4> dTexDesc;
 	DevBuf<float> dTables;  // cos[512] sin[512] gamma[256]
@@ -1297,7 +1300,7 @@ struct rtx_scene {
 
 	~rtx_scene() {
 		(void)hipSetDevice(device);
-		dPairs.release(); dWide.release(); dTriHit.release(); dTriShade.release(); dTexels.release(); dTexDesc.release();
+		dPairs.release(); dWide.release(); dTriHit.release(); dTriShade.release(); dTriUv.release(); dTexels.release(); dTexDesc.release();
 		dTables.release(); dAccumOwn.release(); arena.release(); dCounts.release(); dStats.release();
 		if (hCounts) (void)hipHostFree(hCounts);
 		if (hStats) (void)hipHostFree(hStats);
@@ -1335,6 +1338,7 @@ DevScene make_dev_scene(const rtx_scene* s) {
 	d.wide = s->dWide.p;
 	d.triHit = s->dTriHit.p;
 	d.triShade = s->dTriShade.p;
+	d.triUv = s->dTriUv.p;
 	d.texels = s->dTexels.p;
 	d.texDesc = s->dTexDesc.p;
 	d.cosT = s->dTables.p;
@@ -1525,11 +1529,8 @@ int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float
 	if (need <= 16) {
 		if (st) RTX_LAUNCH(16, true); else RTX_LAUNCH(16, false);
 	}
-	else if (need <= 24) {
-		if (st) RTX_LAUNCH(24, true); else RTX_LAUNCH(24, false);
-	}
 	else {
-		if (st) RTX_LAUNCH(32, true); else RTX_LAUNCH(32, false);
+		if (st) RTX_LAUNCH(24, true); else RTX_LAUNCH(24, false);
 	}
 #undef RTX_LAUNCH
 	HIPCHK(hipGetLastError());
@@ -1768,7 +1769,7 @@ RTX_API int rtx_scene_create(rtx_scene** out, int device) {
 	if (const char* e = std::getenv("RTX_TRACE_TRI_BATCH")) s->traceTriBatch = std::max(1, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_TRACE_BLOCKS_PER_CU")) s->traceBlocksPerCU = std::max(1, std::atoi(e));
 	if (const char* e = std::getenv("RTX_TRACE_BINARY")) s->forceBinary = std::atoi(e) != 0;
-	if (const char* e = std::getenv("RTX_WIDE_STACK")) s->wideStackCap = std::max(16, std::min(32, std::atoi(e)));
+	if (const char* e = std::getenv("RTX_WIDE_STACK")) s->wideStackCap = std::max(16, std::min(24, std::atoi(e)));
 	std::memset(&s->stats, 0, sizeof(s->stats));
 	*out = s;
 	return RTX_OK;
@@ -1998,7 +1999,8 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 					 (int)wideOk, wide.size() / 16, wideStackNeed, npairs, maxInteriorDepth + 1);
 
 	// Triangle records in rank order.
-	std::vector<float4> th((size_t)std::max<uint32_t>(ntri, 1) * 4), ts((size_t)std::max<uint32_t>(ntri, 1) * 6);
+	std::vector<float4> th((size_t)std::max<uint32_t>(ntri, 1) * 4), ts((size_t)std::max<uint32_t>(ntri, 1) * 4),
+		tu((size_t)std::max<uint32_t>(ntri, 1) * 2);
 	for (uint32_t i = 0; i < ntri; ++i) {
 		const HostTri& t = s->tris[i];
 		const size_t r = (size_t)rankOf[i];
@@ -2021,12 +2023,12 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 		float texf, flagf;
 		std::memcpy(&texf, &t.tex, 4);
 		std::memcpy(&flagf, &flags, 4);
-		ts[r * 6 + 0] = make_float4(t.n[0][0], t.n[0][1], t.n[0][2], t.color[0]);
-		ts[r * 6 + 1] = make_float4(t.n[1][0], t.n[1][1], t.n[1][2], t.color[1]);
-		ts[r * 6 + 2] = make_float4(t.n[2][0], t.n[2][1], t.n[2][2], t.color[2]);
-		ts[r * 6 + 3] = make_float4(t.uv[0][0], t.uv[0][1], t.uv[1][0], t.uv[1][1]);
-		ts[r * 6 + 4] = make_float4(t.uv[2][0], t.uv[2][1], t.rough, t.ior);
-		ts[r * 6 + 5] = make_float4(texf, flagf, idf, 0.0f);
+		ts[r * 4 + 0] = make_float4(t.n[0][0], t.n[0][1], t.n[0][2], t.color[0]);
+		ts[r * 4 + 1] = make_float4(t.n[1][0], t.n[1][1], t.n[1][2], t.color[1]);
+		ts[r * 4 + 2] = make_float4(t.n[2][0], t.n[2][1], t.n[2][2], t.color[2]);
+		ts[r * 4 + 3] = make_float4(t.rough, t.ior, texf, flagf);
+		tu[r * 2 + 0] = make_float4(t.uv[0][0], t.uv[0][1], t.uv[1][0], t.uv[1][1]);
+		tu[r * 2 + 1] = make_float4(t.uv[2][0], t.uv[2][1], 0.0f, 0.0f);
 	}
 
 	HIPCHK(hipSetDevice(s->device));
@@ -2043,6 +2045,8 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 	HIPCHK(hipMemcpy(s->dTriHit.p, th.data(), th.size() * sizeof(float4), hipMemcpyHostToDevice));
 	HIPCHK(s->dTriShade.alloc(ts.size()));
 	HIPCHK(hipMemcpy(s->dTriShade.p, ts.data(), ts.size() * sizeof(float4), hipMemcpyHostToDevice));
+	HIPCHK(s->dTriUv.alloc(tu.size()));
+	HIPCHK(hipMemcpy(s->dTriUv.p, tu.data(), tu.size() * sizeof(float4), hipMemcpyHostToDevice));
 	s->rankOf.swap(rankOf);
 	s->numPairs = (uint32_t)npairs;
 	s->treeDepth = maxDepth + 1;  // + the root-only pair
