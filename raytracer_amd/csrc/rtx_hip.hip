@@ -733,7 +733,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 				const unsigned nyd = r.ny ? hiy : loy, fyd = r.ny ? loy : hiy;
 				const unsigned nzd = r.nz ? hiz : loz, fzd = r.nz ? loz : hiz;
 				int cd[4] = {__float_as_int(w2.z), __float_as_int(w2.w), __float_as_int(w3.x), __float_as_int(w3.y)};
-				// key = entry bound as ordered bits (it is >= 0.001), all ones for a child that is not entered
+				// key: ordered bits of what the children are sorted by, all ones for a child that is not entered
 				unsigned key[4];
 				int nh = 0;
 #pragma unroll
@@ -744,7 +744,10 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 									__fmaf_rn(ubyte_f(fzd, c), Sz, Afz));
 					e = fmaxf(e, 0.001f);
 					const bool h = (cd[c] != 0) & !(x < e) & !(e > best.t);
-					key[c] = h ? __float_as_uint(e) : 0xFFFFFFFFu;
+					// closest hit: nearest child first.  Any hit: the child the ray stays in longest first, where an
+					// occluder is likeliest (any order gives the same answer; the key stays below the "not
+					// entered" marker because the length is clamped to >= +0).
+					key[c] = !h ? 0xFFFFFFFFu : ANYHIT ? 0x7FFFFFFFu - __float_as_uint(fmaxf(x - e, 0.0f)) : __float_as_uint(e);
 					nh += h ? 1 : 0;
 					if (STATS) boxTests += cd[c] != 0;
 				}
