@@ -1068,6 +1068,37 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 	}
 }
 
+// The rays of the last recursion level end their paths whatever they hit: a hit returns zero
+// (src/RayTracer.cpp:170), a miss the sky or the background (:148-152).  Only A is written (B and C of the
+// last level are never read).  Blocks stride over the queue so that each adds its counts once.
+__global__ __launch_bounds__(256) void k_shade_last(DevScene sc, const float4* __restrict__ rayD, const float4* __restrict__ hits,
+													int n, float4* __restrict__ A, unsigned* __restrict__ cnt) {
+	unsigned dead = 0, fetches = 0;
+	for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+		const int rank = __float_as_int(hits[j].x);
+		float3 val = make_float3(0.0f, 0.0f, 0.0f);
+		if (rank == -2) dead++;
+		else if (rank == -1) {
+			if (sc.hasSky) {
+				const float4 D = rayD[j];
+				val = sky_fetch(sc, D.x, D.y, D.z);
+				fetches++;
+			}
+			else
+				val = make_float3(sc.bg.x, sc.bg.y, sc.bg.z);
+		}
+		A[j] = make_float4(val.x, val.y, val.z, 0.0f);
+	}
+	for (int off = 32; off > 0; off >>= 1) {
+		dead += __shfl_down(dead, off, 64);
+		fetches += __shfl_down(fetches, off, 64);
+	}
+	if ((threadIdx.x & 63) == 0) {
+		if (dead) atomicAdd(&cnt[1], dead);
+		if (fetches) atomicAdd(&cnt[3], fetches);
+	}
+}
+
 // Combine step of RayTracer::color for the nodes of one level, children read from the next
 // level (src/RayTracer.cpp:177-224).  Sums start from zero and run in child order, scale
 // factors are applied after the sum, exactly as the reference does.
@@ -1681,8 +1712,12 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 			const unsigned nextCap = (unsigned)std::min<size_t>((size_t)n * (size_t)bmax, widestCap);
 			rc = begin_event(s, 1, ev);
 			if (rc) return rc;
-			hipLaunchKernelGGL(k_shade, dim3((n + SHADE_THREADS - 1) / SHADE_THREADS), dim3(SHADE_THREADS), 0, s->stream, d, lv, rayO[cur], rayD[cur],
-							   hit[cur], n, A[lv], B[lv], C[lv], rayO[nxt], rayD[nxt], cnt, nextCap);
+			if (lv == s->maxDepth)
+				hipLaunchKernelGGL(k_shade_last, dim3(std::min((n + 255) / 256, s->numCUs * 8)), dim3(256), 0, s->stream, d, rayD[cur], hit[cur],
+								   n, A[lv], cnt);
+			else
+				hipLaunchKernelGGL(k_shade, dim3((n + SHADE_THREADS - 1) / SHADE_THREADS), dim3(SHADE_THREADS), 0, s->stream, d, lv, rayO[cur],
+								   rayD[cur], hit[cur], n, A[lv], B[lv], C[lv], rayO[nxt], rayD[nxt], cnt, nextCap);
 			HIPCHK(hipGetLastError());
 			rc = end_event(s, ev);
 			if (rc) return rc;
