@@ -354,7 +354,10 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 														  const float4* __restrict__ rayD, float4* __restrict__ hits,
 														  int n, unsigned long long* __restrict__ stats,
 														  unsigned* __restrict__ work, int refill, int chunk, int triBatch,
-														  const int* __restrict__ list, const unsigned* __restrict__ listCount) {
+														  const int* __restrict__ list, const unsigned* __restrict__ listCount,
+														  const unsigned* __restrict__ nDev) {
+	// the queue length may live on the device (written by the previous level's shade kernel)
+	if (nDev) n = (int)*nDev;
 	// with a list: the rays to trace are list[0 .. *listCount), the ones the wide traversal set aside
 	if (list) n = (int)*listCount;
 	__shared__ int stk[STACK][TRACE_THREADS];
@@ -563,7 +566,8 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 															   int n, unsigned long long* __restrict__ stats,
 															   unsigned* __restrict__ work, int* __restrict__ unsafeList,
 															   unsigned* __restrict__ unsafeCount, int refill, int chunk,
-															   int triBatch) {
+															   int triBatch, const unsigned* __restrict__ nDev) {
+	if (nDev) n = (int)*nDev;
 	__shared__ int stk[STACK][TRACE_THREADS];
 	const int tid = threadIdx.x;
 	const unsigned lane = (unsigned)tid & 63u;
@@ -861,7 +865,9 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 											   const float4* __restrict__ rayD, const float4* __restrict__ hits, int n,
 											   float4* __restrict__ A, int4* __restrict__ B, float4* __restrict__ C,
 											   float4* __restrict__ nRayO, float4* __restrict__ nRayD,
-											   unsigned* __restrict__ cnt, unsigned nextCap) {
+											   unsigned* __restrict__ cnt, unsigned nextCap, const unsigned* __restrict__ nDev) {
+	if (nDev) n = (int)*nDev;
+	if ((int)(blockIdx.x * SHADE_THREADS) >= n) return;  // the grid is sized for the level's capacity
 	const int j = blockIdx.x * SHADE_THREADS + threadIdx.x;
 	const int S = sc.nSpec, Dn = sc.nDiff;
 	int kind = KIND_LEAF;
@@ -1072,7 +1078,8 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 // (src/RayTracer.cpp:170), a miss the sky or the background (:148-152).  Only A is written (B and C of the
 // last level are never read).  Blocks stride over the queue so that each adds its counts once.
 __global__ __launch_bounds__(256) void k_shade_last(DevScene sc, const float4* __restrict__ rayD, const float4* __restrict__ hits,
-													int n, float4* __restrict__ A, unsigned* __restrict__ cnt) {
+													int n, float4* __restrict__ A, unsigned* __restrict__ cnt, const unsigned* __restrict__ nDev) {
+	if (nDev) n = (int)*nDev;
 	unsigned dead = 0, fetches = 0;
 	for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
 		const int rank = __float_as_int(hits[j].x);
@@ -1104,67 +1111,68 @@ __global__ __launch_bounds__(256) void k_shade_last(DevScene sc, const float4* _
 // factors are applied after the sum, exactly as the reference does.
 __global__ __launch_bounds__(256) void k_gather(int S, int Dn, int n, float4* __restrict__ A,
 												const int4* __restrict__ B, const float4* __restrict__ C,
-												const float4* __restrict__ childA) {
-	const int j = blockIdx.x * 256 + threadIdx.x;
-	if (j >= n) return;
-	int4 b = B[j];
-	const int kind = b.y & 0xFF;
-	if (kind == KIND_LEAF) return;
-	const float4 col = A[j];
-	const float4* ch = childA + (unsigned)b.x;
-	float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-	for (int i = 0; i < S; ++i) {
-		float4 c = ch[i];
-		sx = sx + c.x;
-		sy = sy + c.y;
-		sz = sz + c.z;
-	}
-	const float fS = (float)S;
-	float ox, oy, oz;
-	if (kind == KIND_METAL) {
-		ox = (sx * col.x) / fS;
-		oy = (sy * col.y) / fS;
-		oz = (sz * col.z) / fS;
-	}
-	else if (kind == KIND_TRANSP) {
-		sx = sx / fS;
-		sy = sy / fS;
-		sz = sz / fS;
-		const float rp = __int_as_float(b.z);
-		float4 rc = (b.y & FLAG_TIR) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : ch[S];
-		const float q = 1.0f - rp;
-		ox = rp * rc.x + q * sx;
-		oy = rp * rc.y + q * sy;
-		oz = rp * rc.z + q * sz;
-	}
-	else {
-		const float w = 0.04f / fS;
-		sx = sx * w;
-		sy = sy * w;
-		sz = sz * w;
-		float dx = 0.0f, dy = 0.0f, dz = 0.0f;
-		for (int i = 0; i < Dn; ++i) {
-			float4 c = ch[S + i];
-			dx = dx + c.x;
-			dy = dy + c.y;
-			dz = dz + c.z;
+												const float4* __restrict__ childA, const unsigned* __restrict__ nDev) {
+	if (nDev) n = (int)*nDev;
+	for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+		int4 b = B[j];
+		const int kind = b.y & 0xFF;
+		if (kind == KIND_LEAF) continue;
+		const float4 col = A[j];
+		const float4* ch = childA + (unsigned)b.x;
+		float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+		for (int i = 0; i < S; ++i) {
+			float4 c = ch[i];
+			sx = sx + c.x;
+			sy = sy + c.y;
+			sz = sz + c.z;
 		}
-		const float fD = (float)Dn;
-		dx = (dx * col.x) / fD;
-		dy = (dy * col.y) / fD;
-		dz = (dz * col.z) / fD;
-		const float ad = __int_as_float(b.z);
-		ox = sx + dx * ad;
-		oy = sy + dy * ad;
-		oz = sz + dz * ad;
-		if (b.y & FLAG_TEX) {
-			float4 tx = C[j];
-			ox = ox * tx.x;
-			oy = oy * tx.y;
-			oz = oz * tx.z;
+		const float fS = (float)S;
+		float ox, oy, oz;
+		if (kind == KIND_METAL) {
+			ox = (sx * col.x) / fS;
+			oy = (sy * col.y) / fS;
+			oz = (sz * col.z) / fS;
 		}
+		else if (kind == KIND_TRANSP) {
+			sx = sx / fS;
+			sy = sy / fS;
+			sz = sz / fS;
+			const float rp = __int_as_float(b.z);
+			float4 rc = (b.y & FLAG_TIR) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : ch[S];
+			const float q = 1.0f - rp;
+			ox = rp * rc.x + q * sx;
+			oy = rp * rc.y + q * sy;
+			oz = rp * rc.z + q * sz;
+		}
+		else {
+			const float w = 0.04f / fS;
+			sx = sx * w;
+			sy = sy * w;
+			sz = sz * w;
+			float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+			for (int i = 0; i < Dn; ++i) {
+				float4 c = ch[S + i];
+				dx = dx + c.x;
+				dy = dy + c.y;
+				dz = dz + c.z;
+			}
+			const float fD = (float)Dn;
+			dx = (dx * col.x) / fD;
+			dy = (dy * col.y) / fD;
+			dz = (dz * col.z) / fD;
+			const float ad = __int_as_float(b.z);
+			ox = sx + dx * ad;
+			oy = sy + dy * ad;
+			oz = sz + dz * ad;
+			if (b.y & FLAG_TEX) {
+				float4 tx = C[j];
+				ox = ox * tx.x;
+				oy = oy * tx.y;
+				oz = oz * tx.z;
+			}
+		}
+		A[j] = make_float4(ox, oy, oz, 0.0f);
 	}
-	A[j] = make_float4(ox, oy, oz, 0.0f);
 }
 
 // accumulateImg(row,col) += (c0+c1+c2+c3) * 0.25f (src/RayTracer.cpp:242-246).  One thread per pixel.
@@ -1521,15 +1529,15 @@ constexpr int WORK2_SLOT = 7;    // queue cursor of the binary-tree kernel
 // traces list[0 .. *listCount); the count lives on the device, so the grid is a fixed small one.
 template <bool ANYHIT, bool EXH>
 int launch_exact_t(rtx_scene* s, const DevScene& d, const float4* ro, const float4* rd, float4* hits, int n, unsigned* work,
-				   const int* list, const unsigned* listCount) {
-	const int wanted = list ? s->numCUs : (n + TRACE_THREADS - 1) / TRACE_THREADS;
+				   const int* list, const unsigned* listCount, const unsigned* nDev) {
+	const int wanted = list ? s->numCUs : nDev ? s->numCUs * s->traceBlocksPerCU : (n + TRACE_THREADS - 1) / TRACE_THREADS;
 	dim3 grid(std::max(1, std::min(wanted, s->numCUs * s->traceBlocksPerCU))), block(TRACE_THREADS);
 	const int need = s->stackNeed;
 	const bool st = s->instrumented;
 	unsigned long long* stats = s->dStats.p;
 #define RTX_LAUNCH(STK, ST)                                                                                              \
 	hipLaunchKernelGGL((k_trace<STK, ANYHIT, EXH, ST>), grid, block, 0, s->stream, d, ro, rd, hits, n, stats, work,      \
-					   s->traceRefill, s->traceChunk, s->traceTriBatch, list, listCount)
+					   s->traceRefill, s->traceChunk, s->traceTriBatch, list, listCount, nDev)
 	if (need <= 16) {
 		if (st) RTX_LAUNCH(16, true); else RTX_LAUNCH(16, false);
 	}
@@ -1549,8 +1557,8 @@ int launch_exact_t(rtx_scene* s, const DevScene& d, const float4* ro, const floa
 
 template <bool ANYHIT>
 int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float4* rd, float4* hits, int n, unsigned* work,
-				  int* unsafeList, unsigned* unsafeCount) {
-	const int wanted = (n + TRACE_THREADS - 1) / TRACE_THREADS;
+				  int* unsafeList, unsigned* unsafeCount, const unsigned* nDev) {
+	const int wanted = nDev ? s->numCUs * s->traceBlocksPerCU : (n + TRACE_THREADS - 1) / TRACE_THREADS;
 	dim3 grid(std::min(wanted, s->numCUs * s->traceBlocksPerCU)), block(TRACE_THREADS);
 	// The stack is no deeper than wideStackCap entries however deep the tree: a ray that would need more
 	// moves to the binary-tree kernel.  Fewer entries, more resident waves.
@@ -1559,7 +1567,7 @@ int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float
 	unsigned long long* stats = s->dStats.p;
 #define RTX_LAUNCH(STK, ST)                                                                                              \
 	hipLaunchKernelGGL((k_trace_wide<STK, ANYHIT, ST>), grid, block, 0, s->stream, d, ro, rd, hits, n, stats, work,      \
-					   unsafeList, unsafeCount, s->traceRefill, s->traceChunk, s->traceTriBatch)
+					   unsafeList, unsafeCount, s->traceRefill, s->traceChunk, s->traceTriBatch, nDev)
 	if (need <= 16) {
 		if (st) RTX_LAUNCH(16, true); else RTX_LAUNCH(16, false);
 	}
@@ -1575,23 +1583,25 @@ int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float
 // Production: wide traversal, then the binary-tree kernel over the rays the wide one set aside.
 // Exhaustive: the binary-tree kernel without culling over the whole queue.
 int launch_trace(rtx_scene* s, const DevScene& d, bool anyhit, bool exhaustive, const float4* ro, const float4* rd,
-				 float4* hits, int n, unsigned* cnt, int* unsafeList, int level = 0) {
-	if (n <= 0) return RTX_OK;
+				 float4* hits, int n, unsigned* cnt, int* unsafeList, int level = 0, const unsigned* nDev = nullptr) {
+	if (n <= 0 && !nDev) return RTX_OK;
 	size_t ev;
 	int rc = begin_event(s, 0, ev, level);
 	if (rc) return rc;
 	if (exhaustive)
-		rc = launch_exact_t<false, true>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, nullptr, nullptr);
+		rc = launch_exact_t<false, true>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, nullptr, nullptr, nDev);
 	else if (!s->wideOk || s->forceBinary)
-		rc = anyhit ? launch_exact_t<true, false>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, nullptr, nullptr)
-					: launch_exact_t<false, false>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, nullptr, nullptr);
+		rc = anyhit ? launch_exact_t<true, false>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, nullptr, nullptr, nDev)
+					: launch_exact_t<false, false>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, nullptr, nullptr, nDev);
 	else if (anyhit) {
-		rc = launch_wide_t<true>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, unsafeList, cnt + UNSAFE_SLOT);
-		if (rc == RTX_OK) rc = launch_exact_t<true, false>(s, d, ro, rd, hits, n, cnt + WORK2_SLOT, unsafeList, cnt + UNSAFE_SLOT);
+		rc = launch_wide_t<true>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, unsafeList, cnt + UNSAFE_SLOT, nDev);
+		if (rc == RTX_OK)
+			rc = launch_exact_t<true, false>(s, d, ro, rd, hits, n, cnt + WORK2_SLOT, unsafeList, cnt + UNSAFE_SLOT, nullptr);
 	}
 	else {
-		rc = launch_wide_t<false>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, unsafeList, cnt + UNSAFE_SLOT);
-		if (rc == RTX_OK) rc = launch_exact_t<false, false>(s, d, ro, rd, hits, n, cnt + WORK2_SLOT, unsafeList, cnt + UNSAFE_SLOT);
+		rc = launch_wide_t<false>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, unsafeList, cnt + UNSAFE_SLOT, nDev);
+		if (rc == RTX_OK)
+			rc = launch_exact_t<false, false>(s, d, ro, rd, hits, n, cnt + WORK2_SLOT, unsafeList, cnt + UNSAFE_SLOT, nullptr);
 	}
 	if (rc) return rc;
 	return end_event(s, ev);
@@ -1691,54 +1701,46 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 			continue;
 		}
 
+		// Every level is enqueued at once: a level's queue length stays on the device (slot 0 of its counter
+		// block, written by the shade kernel of the level above), arrays are carved at the level's capacity
+		// and grids sized for it.  The host reads the counters once, after the batch.
 		float4* A[MAX_DEPTH + 1];
 		int4* B[MAX_DEPTH + 1];
 		float4* C[MAX_DEPTH + 1];
-		int count[MAX_DEPTH + 2];
-		count[0] = b.nSamples;
-		int last = 0;
+		size_t cap[MAX_DEPTH + 2];
+		cap[0] = (size_t)b.nSamples;
 		for (int lv = 0; lv <= s->maxDepth; ++lv) {
-			const int n = count[lv];
-			last = lv;
-			A[lv] = (float4*)bump.take((size_t)n * 16);
-			B[lv] = (int4*)bump.take((size_t)n * 16);
-			C[lv] = (float4*)bump.take((size_t)n * 16);
+			const size_t n = cap[lv];
+			cap[lv + 1] = std::min(n * (size_t)bmax, widestCap);
+			A[lv] = (float4*)bump.take(n * 16);
+			B[lv] = (int4*)bump.take(n * 16);
+			C[lv] = (float4*)bump.take(n * 16);
 			if (!A[lv] || !B[lv] || !C[lv]) return fail(RTX_ERR_MEMORY, "work arena exhausted (internal sizing error)");
 			const int cur = lv & 1, nxt = cur ^ 1;
-			rc = launch_trace(s, d, lv == s->maxDepth, false, rayO[cur], rayD[cur], hit[cur], n,
-							  s->dCounts.p + (size_t)lv * CNT_STRIDE, unsafeList, lv);
+			const unsigned* nDev = lv ? s->dCounts.p + (size_t)lv * CNT_STRIDE : nullptr;
+			rc = launch_trace(s, d, lv == s->maxDepth, false, rayO[cur], rayD[cur], hit[cur], (int)n,
+							  s->dCounts.p + (size_t)lv * CNT_STRIDE, unsafeList, lv, nDev);
 			if (rc) return rc;
 			unsigned* cnt = s->dCounts.p + (size_t)(lv + 1) * CNT_STRIDE;
-			const unsigned nextCap = (unsigned)std::min<size_t>((size_t)n * (size_t)bmax, widestCap);
 			rc = begin_event(s, 1, ev);
 			if (rc) return rc;
 			if (lv == s->maxDepth)
-				hipLaunchKernelGGL(k_shade_last, dim3(std::min((n + 255) / 256, s->numCUs * 8)), dim3(256), 0, s->stream, d, rayD[cur], hit[cur],
-								   n, A[lv], cnt);
+				hipLaunchKernelGGL(k_shade_last, dim3((unsigned)std::min<size_t>((n + 255) / 256, (size_t)s->numCUs * 8)), dim3(256), 0, s->stream,
+								   d, rayD[cur], hit[cur], (int)n, A[lv], cnt, nDev);
 			else
-				hipLaunchKernelGGL(k_shade, dim3((n + SHADE_THREADS - 1) / SHADE_THREADS), dim3(SHADE_THREADS), 0, s->stream, d, lv, rayO[cur],
-								   rayD[cur], hit[cur], n, A[lv], B[lv], C[lv], rayO[nxt], rayD[nxt], cnt, nextCap);
+				hipLaunchKernelGGL(k_shade, dim3((unsigned)((n + SHADE_THREADS - 1) / SHADE_THREADS)), dim3(SHADE_THREADS), 0, s->stream, d, lv,
+								   rayO[cur], rayD[cur], hit[cur], (int)n, A[lv], B[lv], C[lv], rayO[nxt], rayD[nxt], cnt, (unsigned)cap[lv + 1],
+								   nDev);
 			HIPCHK(hipGetLastError());
 			rc = end_event(s, ev);
 			if (rc) return rc;
-			HIPCHK(hipMemcpyAsync(s->hCounts + (size_t)(lv + 1) * CNT_STRIDE, cnt, CNT_STRIDE * sizeof(unsigned),
-								  hipMemcpyDeviceToHost, s->stream));
-			HIPCHK(hipStreamSynchronize(s->stream));
-			const unsigned* hc = s->hCounts + (size_t)(lv + 1) * CNT_STRIDE;
-			if (hc[4]) return fail(RTX_ERR_MEMORY, "child queue overflow (internal sizing error)");
-			s->stats.rays_per_level[lv] += (uint64_t)n - hc[1];
-			s->stats.rays += (uint64_t)n - hc[1];
-			s->stats.shaded_hits += hc[2];
-			s->stats.texture_fetches += hc[3];
-			count[lv + 1] = (int)hc[0];
-			if (lv == s->maxDepth || hc[0] == 0) break;
 		}
 		rc = begin_event(s, 1, ev);
 		if (rc) return rc;
-		for (int lv = last - 1; lv >= 0; --lv) {
-			const int n = count[lv];
-			hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->nSpec, s->nDiff, n, A[lv],
-							   B[lv], C[lv], A[lv + 1]);
+		for (int lv = s->maxDepth - 1; lv >= 0; --lv) {
+			const unsigned* nDev = lv ? s->dCounts.p + (size_t)lv * CNT_STRIDE : nullptr;
+			hipLaunchKernelGGL(k_gather, dim3((unsigned)std::min<size_t>((cap[lv] + 255) / 256, (size_t)s->numCUs * 16)), dim3(256), 0, s->stream,
+							   s->nSpec, s->nDiff, (int)cap[lv], A[lv], B[lv], C[lv], A[lv + 1], nDev);
 			HIPCHK(hipGetLastError());
 		}
 		const int npix = b.nSamples / 4;
@@ -1749,7 +1751,20 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 		HIPCHK(hipGetLastError());
 		rc = end_event(s, ev);
 		if (rc) return rc;
+		HIPCHK(hipMemcpyAsync(s->hCounts, s->dCounts.p, (MAX_DEPTH + 2) * CNT_STRIDE * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
 		HIPCHK(hipStreamSynchronize(s->stream));
+		{
+			uint64_t n = (uint64_t)b.nSamples;
+			for (int lv = 0; lv <= s->maxDepth; ++lv) {
+				const unsigned* hc = s->hCounts + (size_t)(lv + 1) * CNT_STRIDE;
+				if (hc[4]) return fail(RTX_ERR_MEMORY, "child queue overflow (internal sizing error)");
+				s->stats.rays_per_level[lv] += n - hc[1];
+				s->stats.rays += n - hc[1];
+				s->stats.shaded_hits += hc[2];
+				s->stats.texture_fetches += hc[3];
+				n = hc[0];
+			}
+		}
 		rc = harvest_events(s);
 		if (rc) return rc;
 	}
