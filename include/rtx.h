@@ -132,14 +132,26 @@ int rtx_accum_reset(rtx_scene* s);
 
 /* The loop body of RayTracer::render for frames i = first_frame .. first_frame+n_frames-1
  * (1-based like `i` at src/RayTracer.cpp:234): camera rays, traversal, intersection, bounce
- * loop, accumulateImg(row,col) += sum*0.25f (src/RayTracer.cpp:237-246).  The tone map and PNG
- * write stay with the caller. */
+ * loop, accumulateImg(row,col) += sum*0.25f (src/RayTracer.cpp:237-246).  The tone map is
+ * rtx_tonemap_read (or the caller's own); the PNG write stays with the caller. */
 int rtx_render_frames(rtx_scene* s, uint32_t first_frame, uint32_t n_frames);
 
 /* Copies the accumulator to host memory: height*width*4 floats. */
 int rtx_accum_read(rtx_scene* s, float* host_rgba);
 /* Uploads an accumulator (resuming from a saved image). */
 int rtx_accum_write(rtx_scene* s, const float* host_rgba);
+
+/* The 8-bit tone map of src/RayTracer.cpp:248-257 on the device.  `out8 = clamp(lroundf(powf(acc/frame,
+ * 1/2.2f)*255))` is a step function of acc/frame, so the host's own libm is tabulated once
+ * (rtxh_tonemap_table) and the device only searches the table: the bytes equal what the host computes.
+ * bits[n] ascending float bit patterns of the non-negative breakpoints (bits[0] = 0), values[n] the byte from
+ * each breakpoint on; `negative` and `nan` are the bytes for inputs with the sign bit set and for NaN.
+ * Inputs beyond 1e15, where the reference's narrowing of lroundf's result to int wraps around, saturate to
+ * the last entry. */
+int rtx_scene_set_tonemap_table(rtx_scene* s, const uint32_t* bits, const uint8_t* values, int n, uint8_t negative, uint8_t nan);
+/* Tone-maps the accumulator after `frame` frames and copies height*width*3 bytes (RGB, row-major, the
+ * outputBuffer of src/RayTracer.cpp:257) to host memory. */
+int rtx_tonemap_read(rtx_scene* s, int frame, uint8_t* host_rgb8);
 
 /* Closest hit of every primary ray (the head of RayTracer::color, src/RayTracer.cpp:137-151,
  * applied to Camera::getRay, src/Camera.cpp:40-49): tri_ids[height*width*4] (reference triangle
@@ -183,6 +195,10 @@ int rtxh_tables(float cos512[512], float sin512[512], float gamma256[256]);
 
 /* Tone map of src/RayTracer.cpp:248-257: rgb8[npix*3] from accum[npix*4] after `frame` frames. */
 int rtxh_tonemap(const float* accum_rgba, int frame, size_t npix, uint8_t* rgb8);
+/* The same function as a table for rtx_scene_set_tonemap_table: up to `cap` breakpoints (1024 is plenty)
+ * found by bisection over the float bit patterns with this host's powf/lroundf; special[0] = byte for negative
+ * inputs, special[1] = byte for NaN. */
+int rtxh_tonemap_table(uint32_t* bits, uint8_t* values, int cap, int* n_out, uint8_t special[2]);
 
 /* Whole drop-in: parse `config_path` with the grammar of RayTracer::parseConfigFile
  * (src/RayTracer.cpp:284-518), render on `n_devices` GPUs (device ids 0..n-1) and write

@@ -59,6 +59,8 @@ HIP_SYMBOLS = {
     "rtx_render_frames": (_i, [_vp, _u32, _u32]),
     "rtx_accum_read": (_i, [_vp, _fp]),
     "rtx_accum_write": (_i, [_vp, _fp]),
+    "rtx_scene_set_tonemap_table": (_i, [_vp, _vp, _vp, _i, C.c_uint8, C.c_uint8]),
+    "rtx_tonemap_read": (_i, [_vp, _i, _vp]),
     "rtx_primary_hits": (_i, [_vp, _i, _ip, _fp]),
     "rtx_trace_rays": (_i, [_vp, _i, _u32, _fp, _fp, _ip, _fp]),
     "rtx_sample_radiance": (_i, [_vp, _u32, _fp]),
@@ -73,6 +75,7 @@ HOST_SYMBOLS = {
     "rtxh_make_triangle": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _f, _f, _vp]),
     "rtxh_tables": (_i, [_fp, _fp, _fp]),
     "rtxh_tonemap": (_i, [_fp, _i, C.c_size_t, _vp]),
+    "rtxh_tonemap_table": (_i, [_vp, _vp, _i, _ip, _vp]),
     "rtxh_run_config": (_i, [C.c_char_p, C.c_char_p, _i]),
 }
 
@@ -175,6 +178,14 @@ def tonemap(accum, frame):
     return out
 
 
+def tonemap_table():
+    """The tone map as a step function of accum/frame: (bits uint32[n], values uint8[n], negative, nan)."""
+    bits, vals = np.zeros(1024, np.uint32), np.zeros(1024, np.uint8)
+    n, special = C.c_int(0), np.zeros(2, np.uint8)
+    _chkh(host_lib().rtxh_tonemap_table(bits.ctypes.data, vals.ctypes.data, 1024, C.byref(n), special.ctypes.data))
+    return bits[:n.value].copy(), vals[:n.value].copy(), int(special[0]), int(special[1])
+
+
 def run_config(config_path, out_dir=".", n_devices=1):
     _chkh(host_lib().rtxh_run_config(os.fsencode(config_path), os.fsencode(out_dir), n_devices))
 
@@ -274,6 +285,16 @@ class RayTracer:
     def accum(self):
         out = np.zeros((self.height, self.width, 4), np.float32)
         _chk(self.lib.rtx_accum_read(self.h, _p(out.reshape(-1))))
+        return out
+
+    def tonemap_read(self, frame):
+        """The 8-bit image after `frame` frames, tone-mapped on the device: (H, W, 3) uint8."""
+        if not getattr(self, "_tone_set", False):
+            bits, vals, neg, nan = tonemap_table()
+            _chk(self.lib.rtx_scene_set_tonemap_table(self.h, bits.ctypes.data, vals.ctypes.data, len(bits), neg, nan))
+            self._tone_set = True
+        out = np.zeros((self.height, self.width, 3), np.uint8)
+        _chk(self.lib.rtx_tonemap_read(self.h, frame, out.ctypes.data))
         return out
 
     def write_accum(self, accum):

@@ -15,7 +15,10 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -325,6 +328,8 @@ struct HipApi {
 	RTX_FN(rtx_scene_set_tiles)
 	RTX_FN(rtx_render_frames)
 	RTX_FN(rtx_accum_read)
+	RTX_FN(rtx_scene_set_tonemap_table)
+	RTX_FN(rtx_tonemap_read)
 	RTX_FN(rtx_get_stats)
 #undef RTX_FN
 };
@@ -353,6 +358,8 @@ void bind_hip(HipApi& api) {
 	RTX_FN(rtx_scene_set_tiles)
 	RTX_FN(rtx_render_frames)
 	RTX_FN(rtx_accum_read)
+	RTX_FN(rtx_scene_set_tonemap_table)
+	RTX_FN(rtx_tonemap_read)
 	RTX_FN(rtx_get_stats)
 #undef RTX_FN
 }
@@ -606,7 +613,8 @@ void HostRayTracer::render(const std::string& outDir, int nDevices) {
 
 	struct Dev {
 		rtx_scene* scene = nullptr;
-		std::vector<float> accum;
+		std::vector<float> accum;   // host tone map only
+		std::vector<uint8_t> rgb;   // device tone map: the whole image, this device's tiles valid
 	};
 	std::vector<Dev> devs(nDevices);
 	struct Cleanup {
@@ -617,6 +625,16 @@ void HostRayTracer::render(const std::string& outDir, int nDevices) {
 				if (d.scene) hip.rtx_scene_destroy(d.scene);
 		}
 	} cleanup{hip, devs};
+
+	// The 8-bit conversion runs on the device from a table of this host's powf/lroundf (same bytes, a quarter
+	// of the transfer, none of the 6 M powf calls per 1080p frame); should the table not be constructible
+	// the accumulator is read back and converted here.
+	std::vector<uint32_t> toneBits(1024);
+	std::vector<uint8_t> toneVal(1024);
+	int toneN = 0;
+	uint8_t toneSpecial[2] = {0, 0};
+	const bool deviceToneMap = tonemap_table(toneBits.data(), toneVal.data(), 1024, &toneN, toneSpecial);
+
 	const float bg[3] = {backgroundColor.x, backgroundColor.y, backgroundColor.z};
 	for (int d = 0; d < nDevices; ++d) {
 		chk(hip.rtx_scene_create(&devs[d].scene, d));
@@ -629,11 +647,65 @@ void HostRayTracer::render(const std::string& outDir, int nDevices) {
 		chk(hip.rtx_scene_set_bvh(s, nodes.data(), (uint32_t)nodes.size()));
 		chk(hip.rtx_scene_set_tables(s, ct.data(), st.data(), gt.data()));
 		chk(hip.rtx_scene_set_tiles(s, d, nDevices, -1));
-		devs[d].accum.assign((size_t)width * height * 4, 0.0f);
+		if (deviceToneMap) {
+			chk(hip.rtx_scene_set_tonemap_table(s, toneBits.data(), toneVal.data(), toneN, toneSpecial[0], toneSpecial[1]));
+			devs[d].rgb.assign((size_t)width * height * 3, 0);
+		}
+		else
+			devs[d].accum.assign((size_t)width * height * 4, 0.0f);
 	}
 
-	std::vector<float> accumulateImg((size_t)width * height * 4, 0.0f);
-	std::vector<uint8_t> outputBuffer((size_t)width * height * 3);
+	// Images are encoded and written by a second thread while the next frame renders; the frame's line on
+	// stdout follows its file, in frame order, as in the reference (src/RayTracer.cpp:263-271).
+	struct Job {
+		int frame;
+		float seconds;
+		std::vector<uint8_t> pixels;
+	};
+	std::mutex mu;
+	std::condition_variable cv;
+	std::deque<Job> jobs;
+	bool done = false;
+	std::string writeError;
+	std::thread writer([&] {
+		for (;;) {
+			Job job;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&] { return done || !jobs.empty(); });
+				if (jobs.empty()) return;
+				job = std::move(jobs.front());
+			}
+			char name[32];
+			std::snprintf(name, sizeof(name), "out_%03d.png", job.frame);
+			const std::string file = outDir.empty() ? std::string(name) : (outDir + "/" + name);
+			const bool ok = write_png(file, width, height, job.pixels.data());
+			if (ok) std::cout << "Output frame " << job.frame << ", use " << job.seconds << "s\n";
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				if (!ok && writeError.empty()) writeError = "Can't write " + file;
+				jobs.pop_front();  // only now: the renderer may run at most two frames ahead of the disk
+			}
+			cv.notify_all();
+		}
+	});
+	struct JoinWriter {
+		std::mutex& mu;
+		std::condition_variable& cv;
+		bool& done;
+		std::thread& t;
+		~JoinWriter() {
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				done = true;
+			}
+			cv.notify_all();
+			if (t.joinable()) t.join();
+		}
+	} joinWriter{mu, cv, done, writer};
+
+	std::vector<float> accumulateImg;
+	if (!deviceToneMap) accumulateImg.assign((size_t)width * height * 4, 0.0f);
 	const int tilesX = (width + TILE - 1) / TILE;
 	for (int i = 1; i <= renderNum; ++i) {
 		auto time1 = std::chrono::system_clock::now();
@@ -642,31 +714,45 @@ void HostRayTracer::render(const std::string& outDir, int nDevices) {
 		for (int d = 0; d < nDevices; ++d)
 			workers.emplace_back([&, d] {
 				// rtx_last_error is per thread: fetch it on the thread that made the call
-				if (hip.rtx_render_frames(devs[d].scene, (uint32_t)i, 1) < 0 || hip.rtx_accum_read(devs[d].scene, devs[d].accum.data()) < 0)
-					errors[d] = hip.rtx_last_error();
+				int rc = hip.rtx_render_frames(devs[d].scene, (uint32_t)i, 1);
+				if (rc >= 0)
+					rc = deviceToneMap ? hip.rtx_tonemap_read(devs[d].scene, i, devs[d].rgb.data())
+									   : hip.rtx_accum_read(devs[d].scene, devs[d].accum.data());
+				if (rc < 0) errors[d] = hip.rtx_last_error();
 			});
 		for (auto& w : workers) w.join();
 		for (const auto& e : errors)
 			if (!e.empty()) throw std::runtime_error("GPU path: " + e);
 		// each tile is owned by device (tile index % nDevices)
-		if (nDevices == 1)
-			accumulateImg = devs[0].accum;
+		std::vector<uint8_t> outputBuffer((size_t)width * height * 3);
+		const size_t px = deviceToneMap ? 3 : 4;  // units per pixel of what the devices handed back
+		if (nDevices == 1) {
+			if (deviceToneMap) outputBuffer = devs[0].rgb;
+			else accumulateImg = devs[0].accum;
+		}
 		else
 			for (int y = 0; y < height; ++y)
 				for (int x0 = 0; x0 < width; x0 += TILE) {
 					const int owner = ((y / TILE) * tilesX + x0 / TILE) % nDevices;
-					const size_t o = ((size_t)y * width + x0) * 4;
-					const size_t n = (size_t)std::min(TILE, width - x0) * 4;
-					std::memcpy(&accumulateImg[o], &devs[owner].accum[o], n * sizeof(float));
+					const size_t o = ((size_t)y * width + x0) * px;
+					const size_t n = (size_t)std::min(TILE, width - x0) * px;
+					if (deviceToneMap) std::memcpy(&outputBuffer[o], &devs[owner].rgb[o], n);
+					else std::memcpy(&accumulateImg[o], &devs[owner].accum[o], n * sizeof(float));
 				}
-		auto time2 = std::chrono::system_clock::now();
-		tonemap(accumulateImg.data(), i, (size_t)width * height, outputBuffer.data());
-
-		char name[32];
-		std::snprintf(name, sizeof(name), "out_%03d.png", i);
-		std::string file = outDir.empty() ? std::string(name) : (outDir + "/" + name);
-		if (!write_png(file, width, height, outputBuffer.data())) throw std::runtime_error("Can't write " + file);
-		std::cout << "Output frame " << i << ", use " << std::chrono::duration<float>(time2 - time1).count() << "s\n";
+		if (!deviceToneMap) tonemap(accumulateImg.data(), i, (size_t)width * height, outputBuffer.data());
+		auto time2 = std::chrono::system_clock::now();  // the reference's interval covers the tone map too (:235-261)
+		{
+			std::unique_lock<std::mutex> lk(mu);
+			cv.wait(lk, [&] { return jobs.size() < 2 || !writeError.empty(); });
+			if (!writeError.empty()) throw std::runtime_error(writeError);
+			jobs.push_back(Job{i, std::chrono::duration<float>(time2 - time1).count(), std::move(outputBuffer)});
+		}
+		cv.notify_all();
+	}
+	{
+		std::unique_lock<std::mutex> lk(mu);
+		cv.wait(lk, [&] { return jobs.empty() || !writeError.empty(); });
+		if (!writeError.empty()) throw std::runtime_error(writeError);
 	}
 	std::cout << "Render finished" << std::endl;
 }

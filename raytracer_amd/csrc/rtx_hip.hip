@@ -1198,6 +1198,60 @@ __global__ __launch_bounds__(256) void k_accumulate(DevScene sc, Batch b, const 
 	*dst = a;
 }
 
+// out8 = clamp(lroundf(powf(acc / frame, 1 / 2.2f) * 255)) (src/RayTracer.cpp:248-257) as a table search: the
+// bytes of the step function were tabulated with the host's own libm, `bits` are the float bit patterns at
+// which it steps (ascending, bits[0] = 0).  One thread per four pixels = three packed words of output.
+constexpr int TONE_MAX = 1024;
+__global__ __launch_bounds__(256) void k_tonemap(const float4* __restrict__ accum, int npix, float frame,
+												 const unsigned* __restrict__ bits, const unsigned char* __restrict__ values, int n,
+												 unsigned negative, unsigned nan, unsigned char* __restrict__ rgb8) {
+	__shared__ unsigned sBits[TONE_MAX];
+	__shared__ unsigned char sVal[TONE_MAX];
+	for (int i = threadIdx.x; i < n; i += 256) {
+		sBits[i] = bits[i];
+		sVal[i] = values[i];
+	}
+	__syncthreads();
+	const int p0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+	if (p0 >= npix) return;
+	unsigned char out[12];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		float4 a = p0 + k < npix ? accum[p0 + k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		const float ch[3] = {a.x / frame, a.y / frame, a.z / frame};
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			const unsigned b = __float_as_uint(ch[c]);
+			unsigned v;
+			if (ch[c] != ch[c]) v = nan;
+			else if (b >> 31) v = negative;
+			else {
+				int lo = 0, hi = n;  // last i with sBits[i] <= b
+				while (hi - lo > 1) {
+					const int mid = (lo + hi) >> 1;
+					if (sBits[mid] <= b) lo = mid;
+					else hi = mid;
+				}
+				v = sVal[lo];
+			}
+			out[k * 3 + c] = (unsigned char)v;
+		}
+	}
+	if (p0 + 4 <= npix) {
+		unsigned w[3];
+#pragma unroll
+		for (int i = 0; i < 3; ++i)
+			w[i] = (unsigned)out[i * 4] | ((unsigned)out[i * 4 + 1] << 8) | ((unsigned)out[i * 4 + 2] << 16) | ((unsigned)out[i * 4 + 3] << 24);
+		unsigned* dst = (unsigned*)(rgb8 + (size_t)p0 * 3);  // p0 is a multiple of 4: 12-byte stride, 4-byte aligned
+		dst[0] = w[0];
+		dst[1] = w[1];
+		dst[2] = w[2];
+	}
+	else {
+		for (int i = 0; i < (npix - p0) * 3; ++i) rgb8[(size_t)p0 * 3 + i] = out[i];
+	}
+}
+
 // Per-sample radiance export (rtx_sample_radiance): out[(y*W+x)*4+sub] = A[j].
 __global__ __launch_bounds__(256) void k_export_samples(DevScene sc, Batch b, const float4* __restrict__ A,
 														float4* __restrict__ out) {
@@ -1326,6 +1380,10 @@ struct rtx_scene {
 	uint32_t numPairs = 0;
 	// device
 	DevBuf<float4> dPairs, dWide, dTriHit, dTriShade, dTriUv;
+	DevBuf<unsigned> dToneBits;
+	DevBuf<unsigned char> dToneVal, dRgb8;
+	int toneN = 0;
+	unsigned toneNeg = 0, toneNan = 0;
 	DevBuf<uint8_t> dTexels;
 	DevBuf<int4> dTexDesc;
 	DevBuf<float> dTables;  // cos[512] sin[512] gamma[256]
@@ -1342,7 +1400,7 @@ struct rtx_scene {
 
 	~rtx_scene() {
 		(void)hipSetDevice(device);
-		dPairs.release(); dWide.release(); dTriHit.release(); dTriShade.release(); dTriUv.release(); dTexels.release(); dTexDesc.release();
+		dPairs.release(); dWide.release(); dTriHit.release(); dTriShade.release(); dTriUv.release(); dToneBits.release(); dToneVal.release(); dRgb8.release(); dTexels.release(); dTexDesc.release();
 		dTables.release(); dAccumOwn.release(); arena.release(); dCounts.release(); dStats.release();
 		if (hCounts) (void)hipHostFree(hCounts);
 		if (hStats) (void)hipHostFree(hStats);
@@ -2216,6 +2274,39 @@ RTX_API int rtx_accum_write(rtx_scene* s, const float* host_rgba) {
 	int rc = ensure_ready(s, false);
 	if (rc) return rc;
 	HIPCHK(hipMemcpyAsync(s->dAccum, host_rgba, (size_t)s->width * s->height * sizeof(float4), hipMemcpyHostToDevice, s->stream));
+	HIPCHK(hipStreamSynchronize(s->stream));
+	return RTX_OK;
+}
+
+RTX_API int rtx_scene_set_tonemap_table(rtx_scene* s, const uint32_t* bits, const uint8_t* values, int n, uint8_t negative, uint8_t nan) {
+	if (!s || !bits || !values) return fail(RTX_ERR_ARG, "null argument");
+	if (n < 1 || n > TONE_MAX) return fail(RTX_ERR_ARG, "tone map table size out of range");
+	if (bits[0] != 0) return fail(RTX_ERR_ARG, "tone map table must start at +0");
+	for (int i = 1; i < n; ++i)
+		if (bits[i] <= bits[i - 1] || bits[i] > 0x7F800000u) return fail(RTX_ERR_ARG, "tone map breakpoints must ascend over the non-negative floats");
+	HIPCHK(hipSetDevice(s->device));
+	HIPCHK(s->dToneBits.alloc((size_t)n));
+	HIPCHK(s->dToneVal.alloc((size_t)n));
+	HIPCHK(hipMemcpy(s->dToneBits.p, bits, (size_t)n * 4, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(s->dToneVal.p, values, (size_t)n, hipMemcpyHostToDevice));
+	s->toneN = n;
+	s->toneNeg = negative;
+	s->toneNan = nan;
+	return RTX_OK;
+}
+
+RTX_API int rtx_tonemap_read(rtx_scene* s, int frame, uint8_t* host_rgb8) {
+	if (!s || !host_rgb8) return fail(RTX_ERR_ARG, "null argument");
+	if (frame < 1) return fail(RTX_ERR_ARG, "frame must be >= 1");
+	if (!s->toneN) return fail(RTX_ERR_STATE, "rtx_scene_set_tonemap_table has not been called");
+	int rc = ensure_ready(s, false);
+	if (rc) return rc;
+	const size_t npix = (size_t)s->width * s->height;
+	if (!s->dRgb8.p || s->dRgb8.n < npix * 3 + 16) HIPCHK(s->dRgb8.alloc(npix * 3 + 16));
+	hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((npix + 1023) / 1024)), dim3(256), 0, s->stream, s->dAccum, (int)npix, (float)frame,
+					   s->dToneBits.p, s->dToneVal.p, s->toneN, s->toneNeg, s->toneNan, s->dRgb8.p);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(host_rgb8, s->dRgb8.p, npix * 3, hipMemcpyDeviceToHost, s->stream));
 	HIPCHK(hipStreamSynchronize(s->stream));
 	return RTX_OK;
 }

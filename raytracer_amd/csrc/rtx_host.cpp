@@ -16,6 +16,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/rtx.h"
@@ -354,6 +355,61 @@ void tonemap(const float* accum, int frame, size_t npix, uint8_t* rgb8) {
 		}
 }
 
+// The tone map above as a step table over the bit patterns of non-negative floats (see rtx.h).
+bool tonemap_table(uint32_t* bits, uint8_t* values, int cap, int* n_out, uint8_t special[2]) {
+	auto f = [](uint32_t b) {
+		float x[4] = {0, 0, 0, 0};
+		std::memcpy(&x[0], &b, 4);
+		uint8_t out[3];
+		tonemap(x, 1, 1, out);
+		return out[0];
+	};
+	// Seeds spread over [0, 1e15]; between two neighbouring seeds the function is monotone.  Beyond 1.7e15 the
+	// scaled value no longer fits the `int` the reference narrows lroundf's result to (src/RayTracer.cpp:251)
+	// and the byte it stores there is whatever the wrap-around leaves; the table ends before that, so the
+	// device saturates such inputs (and +inf) to the last entry, 255.
+	const float seedsF[] = {0.0f, 1e-30f, 1e-12f, 1e-6f, 1e-3f, 0.5f, 1.0f, 4.0f, 1e6f, 1e15f};
+	std::vector<uint32_t> seeds;
+	for (float v : seedsF) {
+		uint32_t b;
+		std::memcpy(&b, &v, 4);
+		seeds.push_back(b);
+	}
+	std::vector<std::pair<uint32_t, uint8_t>> steps;
+	steps.push_back({0u, f(0u)});
+	for (size_t k = 0; k + 1 < seeds.size(); ++k) {
+		// all breakpoints in (seeds[k], seeds[k+1]] by bisection of every sub-interval whose ends differ
+		std::vector<std::pair<uint32_t, uint32_t>> st;
+		st.push_back({seeds[k], seeds[k + 1]});
+		std::vector<std::pair<uint32_t, uint8_t>> found;
+		while (!st.empty()) {
+			auto [lo, hi] = st.back();
+			st.pop_back();
+			if (f(lo) == f(hi)) continue;
+			if (hi == lo + 1) {
+				found.push_back({hi, f(hi)});
+				continue;
+			}
+			const uint32_t mid = lo + (hi - lo) / 2;
+			st.push_back({lo, mid});
+			st.push_back({mid, hi});
+		}
+		std::sort(found.begin(), found.end());
+		for (auto& e : found) steps.push_back(e);
+	}
+	if ((int)steps.size() > cap) return false;
+	for (size_t i = 0; i < steps.size(); ++i) {
+		bits[i] = steps[i].first;
+		values[i] = steps[i].second;
+	}
+	*n_out = (int)steps.size();
+	special[0] = f(0xBF800000u);  // -1: powf gives NaN; -0 gives +0; both must agree for one entry to do
+	if (f(0x80000000u) != special[0]) return false;
+	special[1] = f(0x7FC00000u);
+	return true;
+}
+
+
 }  // namespace rtxh
 
 // ================================================================================================
@@ -400,6 +456,13 @@ RTXH_API int rtxh_make_triangle(const float v0[3], const float v1[3], const floa
 RTXH_API int rtxh_tables(float cos512[512], float sin512[512], float gamma256[256]) {
 	if (!cos512 || !sin512 || !gamma256) return fail(RTX_ERR_ARG, "null argument");
 	tables(cos512, sin512, gamma256);
+	return RTX_OK;
+}
+
+RTXH_API int rtxh_tonemap_table(uint32_t* bits, uint8_t* values, int cap, int* n_out, uint8_t special[2]) {
+	if (!bits || !values || !n_out || !special) return fail(RTX_ERR_ARG, "null argument");
+	if (!tonemap_table(bits, values, cap, n_out, special))
+		return fail(RTX_ERR_STATE, "the tone map of this host is not a step table of at most `cap` entries");
 	return RTX_OK;
 }
 

@@ -49,5 +49,6 @@ void make_triangle(const Vec4& v0, const Vec4& v1, const Vec4& v2, const Vec4& s
 int build_bvh(const TriangleRec* tris, uint32_t n, std::vector<NodeRec>& out, int nthreads);
 void tables(float* cos512, float* sin512, float* gamma256);
 void tonemap(const float* accum, int frame, size_t npix, uint8_t* rgb8);
+bool tonemap_table(uint32_t* bits, uint8_t* values, int cap, int* n_out, uint8_t special[2]);
 
 }  // namespace rtxh

@@ -258,6 +258,31 @@ def test_external_accumulator_and_resume(libs):
     assert_bits_equal(want, rt.accum(), "resume")
 
 
+def test_device_tonemap_equals_host(libs):
+    """rtx_tonemap_read (table search on the device) gives the bytes of the host tone map of
+    src/RayTracer.cpp:248-257, on rendered accumulators and on synthetic ones with the awkward values."""
+    sc = scenes.mixed_scene(seed=6, width=150, height=70)      # 10500 pixels: not a multiple of 1024
+    rt = gpu_scene(sc)
+    rt.reset()
+    for frame in (1, 2, 3):
+        rt.render(frame, 1)
+        assert np.array_equal(rt.tonemap_read(frame).reshape(-1, 3), api.tonemap(rt.accum(), frame))
+    rng = np.random.default_rng(2)
+    acc = (10 ** rng.uniform(-12, 3, (sc.height, sc.width, 4))).astype(np.float32)
+    acc[0, :20, 0] = [0.0, -0.0, -1.0, np.nan, np.inf, -np.inf, 1e-45, 1e-38, 1.0, 0.5, 2.0, 255.0, 1e10, 1e15, 3.0, 7.0, 0.25, 0.1, 0.01, 0.001]
+    edges = api.tonemap_table()[0].view(np.float32)
+    acc[1, :100, 1] = edges[:100]
+    acc[2, :100, 2] = np.nextafter(edges[100:200], np.float32(0))
+    rt.write_accum(acc)
+    for frame in (1, 3, 7):
+        want = api.tonemap(acc, frame).reshape(sc.height, sc.width, 3)
+        got = rt.tonemap_read(frame)
+        skip = np.zeros(got.shape, bool)
+        skip[0, 4, 0] = True                                # +inf: the reference's long -> int narrowing; the device saturates
+        assert np.array_equal(got[~skip], want[~skip]), "frame %d: %d bytes differ" % (frame, (got != want).sum())
+        assert got[0, 4, 0] == 255
+
+
 def test_error_paths(libs):
     lib = api.hip_lib()
     h = C.c_void_p()

@@ -102,3 +102,24 @@ def test_host_errors(native_libs):
     nodes = np.zeros(4, scenes.NODE_DTYPE)
     rc = lib.rtxh_build_bvh(tris.ctypes.data, len(tris), nodes.ctypes.data, 4)
     assert rc == -1 and b"too small" in lib.rtxh_last_error()
+
+
+def test_tonemap_table_is_the_host_tonemap(native_libs):
+    """rtxh_tonemap_table tabulates rtxh_tonemap (src/RayTracer.cpp:248-257) exactly on [0, 1e15], at and next to
+    every breakpoint included; the device searches this table instead of calling powf."""
+    bits, vals, neg, nan = api.tonemap_table()
+    assert bits[0] == 0 and (np.diff(bits.astype(np.int64)) > 0).all() and vals[-1] == 255
+    rng = np.random.default_rng(1)
+    edges = bits.view(np.float32)
+    x = np.concatenate([rng.uniform(0, 2, 100000), 10 ** rng.uniform(-44, 15, 100000), [0.0, 1.0, 1e15],
+                        edges, np.nextafter(edges, np.float32(-1))[1:], np.nextafter(edges, np.float32(2))]).astype(np.float32)
+    acc = np.zeros((len(x), 4), np.float32)
+    for frame in (1, 3):
+        acc[:, 0] = x * np.float32(frame)
+        quotient = acc[:, 0] / np.float32(frame)          # what the tone map sees
+        want = api.tonemap(acc, frame)[:, 0]
+        got = vals[np.searchsorted(bits, quotient.view(np.uint32), side="right") - 1]
+        assert np.array_equal(got, want)
+    special = np.zeros((3, 4), np.float32)
+    special[:, 0] = [-1.0, -0.0, np.nan]
+    assert api.tonemap(special, 1)[:, 0].tolist() == [neg, neg, nan]
