@@ -119,7 +119,7 @@ int rtx_scene_set_tables(rtx_scene* s, const float cos512[512], const float sin5
 int rtx_scene_set_tiles(rtx_scene* s, int first, int stride, int count);
 
 /* Upper bound in bytes for the per-frame work arena (ray, hit and path-node queues).
- * 0 selects the default (a fraction of free device memory). */
+ * 0 selects the default (60 % of free device memory, at most 64 GiB). */
 int rtx_scene_set_arena_bytes(rtx_scene* s, uint64_t bytes);
 
 /* Uses caller-owned device memory (height*width*4 floats, row-major, the layout of

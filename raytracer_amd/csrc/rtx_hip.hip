@@ -368,7 +368,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 	unsigned nodeTests = 0, triTests = 0;
 	// wave-uniform: the chunk this wave is handing out
 	int cnext = 0, cend = 0;
-	bool more = true;
+	bool more = true, firstChunk = true;
 	// per lane: the ray in flight (cur < 0: none)
 	int j = -1, cur = -1, sp = 0;
 	RaySlab r;
@@ -391,9 +391,18 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 		const int nidle = __popcll(idle);
 		if (more && nidle >= refill) {
 			if (cnext >= cend) {
+				// A wave's first chunk is the one with its own number; later ones come from the shared cursor,
+				// which therefore starts behind those.  A launch over a short queue then costs no atomics at
+				// all (one address takes only ~90 of them per microsecond, and the grid has thousands of waves).
 				unsigned base = 0;
-				if (lane == 0) base = atomicAdd(work, (unsigned)chunk);
-				base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+				if (firstChunk) {
+					base = (blockIdx.x * (TRACE_THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6)) * (unsigned)chunk;
+					firstChunk = false;
+				}
+				else {
+					if (lane == 0) base = atomicAdd(work, (unsigned)chunk);
+					base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + gridDim.x * (TRACE_THREADS / 64) * (unsigned)chunk;
+				}
 				if (base >= (unsigned)n) {
 					more = false;
 					cnext = cend = 0;
@@ -576,7 +585,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 	unsigned walkIters = 0, leafIters = 0, walkLanes = 0, leafLanes = 0;  // wave-level, kept by lane 0
 	unsigned overflows = 0;
 	int cnext = 0, cend = 0;
-	bool more = true;
+	bool more = true, firstChunk = true;
 	int j = -1, cur = -1, sp = 0;
 	RaySlab r;
 	r.ox = r.oy = r.oz = r.ix = r.iy = r.iz = r.mx = r.my = r.mz = 0.0f;
@@ -593,9 +602,18 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 		const int nidle = __popcll(idle);
 		if (more && nidle >= refill) {
 			if (cnext >= cend) {
+				// A wave's first chunk is the one with its own number; later ones come from the shared cursor,
+				// which therefore starts behind those.  A launch over a short queue then costs no atomics at
+				// all (one address takes only ~90 of them per microsecond, and the grid has thousands of waves).
 				unsigned base = 0;
-				if (lane == 0) base = atomicAdd(work, (unsigned)chunk);
-				base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+				if (firstChunk) {
+					base = (blockIdx.x * (TRACE_THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6)) * (unsigned)chunk;
+					firstChunk = false;
+				}
+				else {
+					if (lane == 0) base = atomicAdd(work, (unsigned)chunk);
+					base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + gridDim.x * (TRACE_THREADS / 64) * (unsigned)chunk;
+				}
 				if (base >= (unsigned)n) {
 					more = false;
 					cnext = cend = 0;
@@ -867,210 +885,214 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 											   float4* __restrict__ nRayO, float4* __restrict__ nRayD,
 											   unsigned* __restrict__ cnt, unsigned nextCap, const unsigned* __restrict__ nDev) {
 	if (nDev) n = (int)*nDev;
-	if ((int)(blockIdx.x * SHADE_THREADS) >= n) return;  // the grid is sized for the level's capacity
-	const int j = blockIdx.x * SHADE_THREADS + threadIdx.x;
-	const int S = sc.nSpec, Dn = sc.nDiff;
-	int kind = KIND_LEAF;
-	int flags = 0;
-	int nchild = 0;
-	float3 val = make_float3(0.0f, 0.0f, 0.0f);
-	float scalar = 0.0f;
-	float3 texel = make_float3(0.0f, 0.0f, 0.0f);
-	// state needed after the allocation
-	float hx = 0, hy = 0, hz = 0, nx = 0, ny = 0, nz = 0, dx = 0, dy = 0, dz = 0, rough = 0, ior = 1;
-	uint32_t key = 0;
-	unsigned dead = 0, shaded = 0, fetches = 0;
-	const bool active = j < n;
-	if (active) {
-		float4 O = rayO[j];
-		float4 D = rayD[j];
-		float4 H = hits[j];
-		int rank = __float_as_int(H.x);
-		key = __float_as_uint(O.w);
-		dx = D.x; dy = D.y; dz = D.z;
-		if (rank == -2) {
-			dead = 1;
-		}
-		else if (rank == -1) {
-			if (sc.hasSky) {
-				val = sky_fetch(sc, dx, dy, dz);
-				fetches = 1;
+	__shared__ unsigned s_tot[SHADE_THREADS / 64];
+	__shared__ unsigned s_base[SHADE_THREADS / 64];
+	__shared__ unsigned s_stat[3][SHADE_THREADS / 64];
+	// The grid does not grow with the queue: a block walks over it in steps of the grid's width (every thread
+	// of a block makes the same number of rounds, so the barriers below are uniform).
+	for (long long base = (long long)blockIdx.x * SHADE_THREADS; base < n; base += (long long)gridDim.x * SHADE_THREADS) {
+		const int j = (int)base + (int)threadIdx.x;
+		const int S = sc.nSpec, Dn = sc.nDiff;
+		int kind = KIND_LEAF;
+		int flags = 0;
+		int nchild = 0;
+		float3 val = make_float3(0.0f, 0.0f, 0.0f);
+		float scalar = 0.0f;
+		float3 texel = make_float3(0.0f, 0.0f, 0.0f);
+		// state needed after the allocation
+		float hx = 0, hy = 0, hz = 0, nx = 0, ny = 0, nz = 0, dx = 0, dy = 0, dz = 0, rough = 0, ior = 1;
+		uint32_t key = 0;
+		unsigned dead = 0, shaded = 0, fetches = 0;
+		const bool active = j < n;
+		if (active) {
+			float4 O = rayO[j];
+			float4 D = rayD[j];
+			float4 H = hits[j];
+			int rank = __float_as_int(H.x);
+			key = __float_as_uint(O.w);
+			dx = D.x; dy = D.y; dz = D.z;
+			if (rank == -2) {
+				dead = 1;
 			}
-			else
-				val = make_float3(sc.bg.x, sc.bg.y, sc.bg.z);
-		}
-		else if (level < sc.maxDepth) {
-			// (at level == maxDepth every hit returns zero, src/RayTracer.cpp:170; the any-hit
-			//  traversal reports such hits with rank 0, which is never dereferenced)
-			// one aligned 64-byte record serves every hit; the texture coordinates live apart
-			const float4* T = sc.triShade + (size_t)rank * 4;
-			float4 s0 = T[0], s1 = T[1], s2 = T[2], s3 = T[3];
-			const float t = H.y, alpha = H.z, beta = H.w;
-			const int triFlags = __float_as_int(s3.w);
-			const int texId = __float_as_int(s3.z);
-			hx = O.x + t * dx;
-			hy = O.y + t * dy;
-			hz = O.z + t * dz;
-			float g = 1.0f - (alpha + beta);
-			nx = (alpha * s0.x + beta * s1.x) + g * s2.x;
-			ny = (alpha * s0.y + beta * s1.y) + g * s2.y;
-			nz = (alpha * s0.z + beta * s1.z) + g * s2.z;
-			float z = dot3w(nx, ny, nz, nx, ny, nz);
-			if (z > 0.0f) {
-				float len = sqrtf(z);
-				nx = nx / len;
-				ny = ny / len;
-				nz = nz / len;
-			}
-			float cosine = dot3w(nx, ny, nz, dx, dy, dz);
-			const bool transp = (triFlags & TRI_TRANSP) != 0;
-			if (!transp && cosine >= 0.0f) {
-				// back side: zero
-			}
-			else if (triFlags & TRI_EMIT) {
-				val = make_float3(s0.w, s1.w, s2.w);
-			}
-			else {
-				shaded = 1;
-				val = make_float3(s0.w, s1.w, s2.w);  // colour, consumed by k_gather
-				rough = s3.x;
-				ior = s3.y;
-				if (triFlags & TRI_METAL) {
-					kind = KIND_METAL;
-					nchild = S;
+			else if (rank == -1) {
+				if (sc.hasSky) {
+					val = sky_fetch(sc, dx, dy, dz);
+					fetches = 1;
 				}
-				else if (transp) {
-					kind = KIND_TRANSP;
-					nchild = S + 1;
+				else
+					val = make_float3(sc.bg.x, sc.bg.y, sc.bg.z);
+			}
+			else if (level < sc.maxDepth) {
+				// (at level == maxDepth every hit returns zero, src/RayTracer.cpp:170; the any-hit
+				//  traversal reports such hits with rank 0, which is never dereferenced)
+				// one aligned 64-byte record serves every hit; the texture coordinates live apart
+				const float4* T = sc.triShade + (size_t)rank * 4;
+				float4 s0 = T[0], s1 = T[1], s2 = T[2], s3 = T[3];
+				const float t = H.y, alpha = H.z, beta = H.w;
+				const int triFlags = __float_as_int(s3.w);
+				const int texId = __float_as_int(s3.z);
+				hx = O.x + t * dx;
+				hy = O.y + t * dy;
+				hz = O.z + t * dz;
+				float g = 1.0f - (alpha + beta);
+				nx = (alpha * s0.x + beta * s1.x) + g * s2.x;
+				ny = (alpha * s0.y + beta * s1.y) + g * s2.y;
+				nz = (alpha * s0.z + beta * s1.z) + g * s2.z;
+				float z = dot3w(nx, ny, nz, nx, ny, nz);
+				if (z > 0.0f) {
+					float len = sqrtf(z);
+					nx = nx / len;
+					ny = ny / len;
+					nz = nz / len;
+				}
+				float cosine = dot3w(nx, ny, nz, dx, dy, dz);
+				const bool transp = (triFlags & TRI_TRANSP) != 0;
+				if (!transp && cosine >= 0.0f) {
+					// back side: zero
+				}
+				else if (triFlags & TRI_EMIT) {
+					val = make_float3(s0.w, s1.w, s2.w);
 				}
 				else {
-					kind = KIND_DIEL;
-					nchild = S + Dn;
-					scalar = fabsf(cosine);
-					if (texId >= 0) {
-						flags |= FLAG_TEX;
-						const float4 u01 = sc.triUv[(size_t)rank * 2], u2 = sc.triUv[(size_t)rank * 2 + 1];
-						float u = (alpha * u01.x + beta * u01.z) + g * u2.x;
-						float v = (alpha * u01.y + beta * u01.w) + g * u2.y;
-						texel = tex_fetch(sc, texId, u, v);
-						fetches = 1;
+					shaded = 1;
+					val = make_float3(s0.w, s1.w, s2.w);  // colour, consumed by k_gather
+					rough = s3.x;
+					ior = s3.y;
+					if (triFlags & TRI_METAL) {
+						kind = KIND_METAL;
+						nchild = S;
+					}
+					else if (transp) {
+						kind = KIND_TRANSP;
+						nchild = S + 1;
+					}
+					else {
+						kind = KIND_DIEL;
+						nchild = S + Dn;
+						scalar = fabsf(cosine);
+						if (texId >= 0) {
+							flags |= FLAG_TEX;
+							const float4 u01 = sc.triUv[(size_t)rank * 2], u2 = sc.triUv[(size_t)rank * 2 + 1];
+							float u = (alpha * u01.x + beta * u01.z) + g * u2.x;
+							float v = (alpha * u01.y + beta * u01.w) + g * u2.y;
+							texel = tex_fetch(sc, texId, u, v);
+							fetches = 1;
+						}
 					}
 				}
 			}
 		}
-	}
 
-	// ---- queue slots for the children.  Inside a wave, per-kind ballots + popcounts give each lane its
-	// offset; the 16 wave totals of the block are scanned in LDS and the block claims its range of the
-	// next level's queue with a single atomic (one word takes only ~90 atomics per microsecond, so one
-	// atomic per wave would bound the kernel).
-	__shared__ unsigned s_tot[SHADE_THREADS / 64];
-	__shared__ unsigned s_base[SHADE_THREADS / 64];
-	__shared__ unsigned s_stat[3][SHADE_THREADS / 64];
-	const unsigned lane = threadIdx.x & 63;
-	const unsigned wave = threadIdx.x >> 6;
-	const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-	unsigned long long bm = __ballot(kind == KIND_METAL);
-	unsigned long long bt = __ballot(kind == KIND_TRANSP);
-	unsigned long long bd = __ballot(kind == KIND_DIEL);
-	unsigned offset = (unsigned)__popcll(bm & lt) * (unsigned)S + (unsigned)__popcll(bt & lt) * (unsigned)(S + 1) +
-					  (unsigned)__popcll(bd & lt) * (unsigned)(S + Dn);
-	unsigned total = (unsigned)__popcll(bm) * (unsigned)S + (unsigned)__popcll(bt) * (unsigned)(S + 1) +
-					 (unsigned)__popcll(bd) * (unsigned)(S + Dn);
-	unsigned long long bdead = __ballot(dead != 0), bsh = __ballot(shaded != 0), bf = __ballot(fetches != 0);
-	if (lane == 0) {
-		s_tot[wave] = total;
-		s_stat[0][wave] = (unsigned)__popcll(bdead);
-		s_stat[1][wave] = (unsigned)__popcll(bsh);
-		s_stat[2][wave] = (unsigned)__popcll(bf);
-	}
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		unsigned run = 0, d = 0, sh = 0, f = 0;
-		for (int w = 0; w < SHADE_THREADS / 64; ++w) {
-			s_base[w] = run;
-			run += s_tot[w];
-			d += s_stat[0][w];
-			sh += s_stat[1][w];
-			f += s_stat[2][w];
+		// ---- queue slots for the children.  Inside a wave, per-kind ballots + popcounts give each lane its
+		// offset; the 16 wave totals of the block are scanned in LDS and the block claims its range of the
+		// next level's queue with a single atomic (one word takes only ~90 atomics per microsecond, so one
+		// atomic per wave would bound the kernel).
+		const unsigned lane = threadIdx.x & 63;
+		const unsigned wave = threadIdx.x >> 6;
+		const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+		unsigned long long bm = __ballot(kind == KIND_METAL);
+		unsigned long long bt = __ballot(kind == KIND_TRANSP);
+		unsigned long long bd = __ballot(kind == KIND_DIEL);
+		unsigned offset = (unsigned)__popcll(bm & lt) * (unsigned)S + (unsigned)__popcll(bt & lt) * (unsigned)(S + 1) +
+						  (unsigned)__popcll(bd & lt) * (unsigned)(S + Dn);
+		unsigned total = (unsigned)__popcll(bm) * (unsigned)S + (unsigned)__popcll(bt) * (unsigned)(S + 1) +
+						 (unsigned)__popcll(bd) * (unsigned)(S + Dn);
+		unsigned long long bdead = __ballot(dead != 0), bsh = __ballot(shaded != 0), bf = __ballot(fetches != 0);
+		if (lane == 0) {
+			s_tot[wave] = total;
+			s_stat[0][wave] = (unsigned)__popcll(bdead);
+			s_stat[1][wave] = (unsigned)__popcll(bsh);
+			s_stat[2][wave] = (unsigned)__popcll(bf);
 		}
-		unsigned base = run ? atomicAdd(&cnt[0], run) : 0u;
-		for (int w = 0; w < SHADE_THREADS / 64; ++w) s_base[w] += base;
-		if (d) atomicAdd(&cnt[1], d);
-		if (sh) atomicAdd(&cnt[2], sh);
-		if (f) atomicAdd(&cnt[3], f);
-	}
-	__syncthreads();
-	const unsigned childBase = s_base[wave] + offset;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			unsigned run = 0, d = 0, sh = 0, f = 0;
+			for (int w = 0; w < SHADE_THREADS / 64; ++w) {
+				s_base[w] = run;
+				run += s_tot[w];
+				d += s_stat[0][w];
+				sh += s_stat[1][w];
+				f += s_stat[2][w];
+			}
+			unsigned base = run ? atomicAdd(&cnt[0], run) : 0u;
+			for (int w = 0; w < SHADE_THREADS / 64; ++w) s_base[w] += base;
+			if (d) atomicAdd(&cnt[1], d);
+			if (sh) atomicAdd(&cnt[2], sh);
+			if (f) atomicAdd(&cnt[3], f);
+		}
+		__syncthreads();
+		const unsigned childBase = s_base[wave] + offset;
 
-	if (nchild) {
-		if (childBase + (unsigned)nchild > nextCap) {
-			// cannot happen when the host sized the queue for the worst case; drop the subtree
-			kind = KIND_LEAF;
-			val = make_float3(0.0f, 0.0f, 0.0f);
-			nchild = 0;
-			atomicOr(&cnt[4], 1u);
+		if (nchild) {
+			if (childBase + (unsigned)nchild > nextCap) {
+				// cannot happen when the host sized the queue for the worst case; drop the subtree
+				kind = KIND_LEAF;
+				val = make_float3(0.0f, 0.0f, 0.0f);
+				nchild = 0;
+				atomicOr(&cnt[4], 1u);
+			}
 		}
-	}
-	if (nchild) {
-		// Triangle::specular (src/Triangle.cpp:121-146)
-		float np = dot3w(dx, dy, dz, nx, ny, nz);
-		float k2 = 2.0f * np;
-		float rx = dx - k2 * nx, ry = dy - k2 * ny, rz = dz - k2 * nz;
-		for (int i = 0; i < S; ++i) {
-			float ox, oy, oz;
-			scatter_offset(sc, key, 0, (uint32_t)i, ox, oy, oz);
-			float cx = rx + ox * rough, cy = ry + oy * rough, cz = rz + oz * rough;
-			nRayO[childBase + i] = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)i)));
-			nRayD[childBase + i] = make_float4(cx, cy, cz, 0.0f);
-		}
-		if (kind == KIND_DIEL) {
-			// Triangle::diffuse (src/Triangle.cpp:95-119)
-			bool keep = dot3w(dx, dy, dz, nx, ny, nz) < 0.0f;
-			float tx = keep ? nx : -nx, ty = keep ? ny : -ny, tz = keep ? nz : -nz;
-			for (int i = 0; i < Dn; ++i) {
+		if (nchild) {
+			// Triangle::specular (src/Triangle.cpp:121-146)
+			float np = dot3w(dx, dy, dz, nx, ny, nz);
+			float k2 = 2.0f * np;
+			float rx = dx - k2 * nx, ry = dy - k2 * ny, rz = dz - k2 * nz;
+			for (int i = 0; i < S; ++i) {
 				float ox, oy, oz;
-				scatter_offset(sc, key, 1, (uint32_t)i, ox, oy, oz);
-				nRayO[childBase + S + i] = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)(S + i))));
-				nRayD[childBase + S + i] = make_float4(tx + ox, ty + oy, tz + oz, 0.0f);
+				scatter_offset(sc, key, 0, (uint32_t)i, ox, oy, oz);
+				float cx = rx + ox * rough, cy = ry + oy * rough, cz = rz + oz * rough;
+				nRayO[childBase + i] = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)i)));
+				nRayD[childBase + i] = make_float4(cx, cy, cz, 0.0f);
+			}
+			if (kind == KIND_DIEL) {
+				// Triangle::diffuse (src/Triangle.cpp:95-119)
+				bool keep = dot3w(dx, dy, dz, nx, ny, nz) < 0.0f;
+				float tx = keep ? nx : -nx, ty = keep ? ny : -ny, tz = keep ? nz : -nz;
+				for (int i = 0; i < Dn; ++i) {
+					float ox, oy, oz;
+					scatter_offset(sc, key, 1, (uint32_t)i, ox, oy, oz);
+					nRayO[childBase + S + i] = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)(S + i))));
+					nRayD[childBase + S + i] = make_float4(tx + ox, ty + oy, tz + oz, 0.0f);
+				}
+			}
+			else if (kind == KIND_TRANSP) {
+				// Triangle::refract (src/Triangle.cpp:149-179)
+				float dot = dot3w(dx, dy, dz, nx, ny, nz);
+				float indexRatio = dot > 0.0f ? ior : (1.0f / ior);
+				float tx = dot > 0.0f ? -nx : nx, ty = dot > 0.0f ? -ny : ny, tz = dot > 0.0f ? -nz : nz;
+				float cosineTheta = fabsf(dot);
+				float squareSine1 = 1.0f - cosineTheta * cosineTheta;
+				float squareSine2 = (indexRatio * indexRatio) * squareSine1;
+				float4 ro = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)S)));
+				if (squareSine2 > 1.0f) {
+					// total internal reflection: proportion 0, child not traced
+					flags |= FLAG_TIR;
+					scalar = 0.0f;
+					nRayO[childBase + S] = ro;
+					nRayD[childBase + S] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+				}
+				else {
+					float cosine2 = sqrtf(1.0f - squareSine2);
+					float ex = indexRatio * (dx + cosineTheta * tx) - tx * cosine2;
+					float ey = indexRatio * (dy + cosineTheta * ty) - ty * cosine2;
+					float ez = indexRatio * (dz + cosineTheta * tz) - tz * cosine2;
+					float temp = (1.0f - indexRatio) / (1.0f + indexRatio);
+					float r0 = temp * temp;
+					float squareTemp = (1.0f - cosineTheta) * (1.0f - cosineTheta);
+					float pow5 = squareTemp * squareTemp * (1.0f - cosineTheta);
+					float reflectProportion = r0 + (1.0f - r0) * pow5;
+					scalar = 1.0f - reflectProportion;
+					nRayO[childBase + S] = ro;
+					nRayD[childBase + S] = make_float4(ex, ey, ez, 0.0f);
+				}
 			}
 		}
-		else if (kind == KIND_TRANSP) {
-			// Triangle::refract (src/Triangle.cpp:149-179)
-			float dot = dot3w(dx, dy, dz, nx, ny, nz);
-			float indexRatio = dot > 0.0f ? ior : (1.0f / ior);
-			float tx = dot > 0.0f ? -nx : nx, ty = dot > 0.0f ? -ny : ny, tz = dot > 0.0f ? -nz : nz;
-			float cosineTheta = fabsf(dot);
-			float squareSine1 = 1.0f - cosineTheta * cosineTheta;
-			float squareSine2 = (indexRatio * indexRatio) * squareSine1;
-			float4 ro = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)S)));
-			if (squareSine2 > 1.0f) {
-				// total internal reflection: proportion 0, child not traced
-				flags |= FLAG_TIR;
-				scalar = 0.0f;
-				nRayO[childBase + S] = ro;
-				nRayD[childBase + S] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-			}
-			else {
-				float cosine2 = sqrtf(1.0f - squareSine2);
-				float ex = indexRatio * (dx + cosineTheta * tx) - tx * cosine2;
-				float ey = indexRatio * (dy + cosineTheta * ty) - ty * cosine2;
-				float ez = indexRatio * (dz + cosineTheta * tz) - tz * cosine2;
-				float temp = (1.0f - indexRatio) / (1.0f + indexRatio);
-				float r0 = temp * temp;
-				float squareTemp = (1.0f - cosineTheta) * (1.0f - cosineTheta);
-				float pow5 = squareTemp * squareTemp * (1.0f - cosineTheta);
-				float reflectProportion = r0 + (1.0f - r0) * pow5;
-				scalar = 1.0f - reflectProportion;
-				nRayO[childBase + S] = ro;
-				nRayD[childBase + S] = make_float4(ex, ey, ez, 0.0f);
-			}
+		if (active) {
+			A[j] = make_float4(val.x, val.y, val.z, 0.0f);
+			B[j] = make_int4((int)childBase, kind | flags, __float_as_int(scalar), 0);
+			if (flags & FLAG_TEX) C[j] = make_float4(texel.x, texel.y, texel.z, 0.0f);
 		}
-	}
-	if (active) {
-		A[j] = make_float4(val.x, val.y, val.z, 0.0f);
-		B[j] = make_int4((int)childBase, kind | flags, __float_as_int(scalar), 0);
-		if (flags & FLAG_TEX) C[j] = make_float4(texel.x, texel.y, texel.z, 0.0f);
+		__syncthreads();  // the LDS words are reused by the next round
 	}
 }
 
@@ -1702,9 +1724,15 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 	double perSample = (mode == 2) ? (double)(NODE_BYTES + 2 * RAY_BYTES + 4) : worst_bytes_per_sample(s);
 	size_t freeB = 0, totalB = 0;
 	HIPCHK(hipMemGetInfo(&freeB, &totalB));
-	size_t budget = s->arenaLimit ? (size_t)s->arenaLimit : (size_t)((double)(freeB + s->arena.n) * 0.6);
+	// Default budget: 60 % of what is free, at most 64 GiB.  Queues are sized for the worst case (every node
+	// spawning its maximum at every level), so deep recursion is split into several pixel batches; each batch
+	// costs one synchronisation plus, per level, the latency of its longest ray.
+	size_t budget = s->arenaLimit ? (size_t)s->arenaLimit
+								  : std::min<size_t>((size_t)((double)(freeB + s->arena.n) * 0.6), (size_t)64 << 30);
 	double needAll = perSample * (double)totalBlocks * SAMPLES_PER_BLOCK + (double)(MAX_DEPTH + 8) * 4096;
 	size_t want = (size_t)std::min((double)budget, needAll);
+	// an arena that is nearly as big as wanted is used as it is rather than reallocated
+	if (s->arena.n && s->arena.n < want && (double)s->arena.n >= 0.9 * (double)want) want = s->arena.n;
 	long long blocksPerBatch = (long long)(((double)want - (double)(MAX_DEPTH + 8) * 4096) / (perSample * SAMPLES_PER_BLOCK));
 	if (blocksPerBatch < 1) {
 		blocksPerBatch = 1;
@@ -1786,7 +1814,7 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 				hipLaunchKernelGGL(k_shade_last, dim3((unsigned)std::min<size_t>((n + 255) / 256, (size_t)s->numCUs * 8)), dim3(256), 0, s->stream,
 								   d, rayD[cur], hit[cur], (int)n, A[lv], cnt, nDev);
 			else
-				hipLaunchKernelGGL(k_shade, dim3((unsigned)((n + SHADE_THREADS - 1) / SHADE_THREADS)), dim3(SHADE_THREADS), 0, s->stream, d, lv,
+				hipLaunchKernelGGL(k_shade, dim3((unsigned)std::min<size_t>((n + SHADE_THREADS - 1) / SHADE_THREADS, (size_t)s->numCUs * 4)), dim3(SHADE_THREADS), 0, s->stream, d, lv,
 								   rayO[cur], rayD[cur], hit[cur], (int)n, A[lv], B[lv], C[lv], rayO[nxt], rayD[nxt], cnt, (unsigned)cap[lv + 1],
 								   nDev);
 			HIPCHK(hipGetLastError());
