@@ -356,8 +356,9 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 														  unsigned* __restrict__ work, int refill, int chunk, int triBatch,
 														  const int* __restrict__ list, const unsigned* __restrict__ listCount,
 														  const unsigned* __restrict__ nDev) {
-	// the queue length may live on the device (written by the previous level's shade kernel)
-	if (nDev) n = (int)*nDev;
+	// the queue length may live on the device (written by the previous level's shade kernel); n is then the
+	// capacity of the arrays
+	if (nDev) n = (int)min(*nDev, (unsigned)n);
 	// with a list: the rays to trace are list[0 .. *listCount), the ones the wide traversal set aside
 	if (list) n = (int)*listCount;
 	__shared__ int stk[STACK][TRACE_THREADS];
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 															   unsigned* __restrict__ work, int* __restrict__ unsafeList,
 															   unsigned* __restrict__ unsafeCount, int refill, int chunk,
 															   int triBatch, const unsigned* __restrict__ nDev) {
-	if (nDev) n = (int)*nDev;
+	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
 	__shared__ int stk[STACK][TRACE_THREADS];
 	const int tid = threadIdx.x;
 	const unsigned lane = (unsigned)tid & 63u;
@@ -884,7 +885,7 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 											   float4* __restrict__ A, int4* __restrict__ B, float4* __restrict__ C,
 											   float4* __restrict__ nRayO, float4* __restrict__ nRayD,
 											   unsigned* __restrict__ cnt, unsigned nextCap, const unsigned* __restrict__ nDev) {
-	if (nDev) n = (int)*nDev;
+	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
 	__shared__ unsigned s_tot[SHADE_THREADS / 64];
 	__shared__ unsigned s_base[SHADE_THREADS / 64];
 	__shared__ unsigned s_stat[3][SHADE_THREADS / 64];
@@ -1101,7 +1102,7 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 // last level are never read).  Blocks stride over the queue so that each adds its counts once.
 __global__ __launch_bounds__(256) void k_shade_last(DevScene sc, const float4* __restrict__ rayD, const float4* __restrict__ hits,
 													int n, float4* __restrict__ A, unsigned* __restrict__ cnt, const unsigned* __restrict__ nDev) {
-	if (nDev) n = (int)*nDev;
+	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
 	unsigned dead = 0, fetches = 0;
 	for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
 		const int rank = __float_as_int(hits[j].x);
@@ -1134,7 +1135,7 @@ __global__ __launch_bounds__(256) void k_shade_last(DevScene sc, const float4* _
 __global__ __launch_bounds__(256) void k_gather(int S, int Dn, int n, float4* __restrict__ A,
 												const int4* __restrict__ B, const float4* __restrict__ C,
 												const float4* __restrict__ childA, const unsigned* __restrict__ nDev) {
-	if (nDev) n = (int)*nDev;
+	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
 	for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
 		int4 b = B[j];
 		const int kind = b.y & 0xFF;
@@ -1198,8 +1199,17 @@ __global__ __launch_bounds__(256) void k_gather(int S, int Dn, int n, float4* __
 }
 
 // accumulateImg(row,col) += (c0+c1+c2+c3) * 0.25f (src/RayTracer.cpp:242-246).  One thread per pixel.
+// True when some level's child queue was too small for this batch (slot 4 of the counter blocks): the batch's
+// result is then incomplete, is not stored, and the host renders the batch again with worst-case queues.
+__device__ __forceinline__ bool batch_overflowed(const unsigned* __restrict__ counts, int maxDepth) {
+	unsigned f = 0;
+	for (int lv = 1; lv <= maxDepth + 1; ++lv) f |= counts[lv * 8 + 4];
+	return f != 0;
+}
+
 __global__ __launch_bounds__(256) void k_accumulate(DevScene sc, Batch b, const float4* __restrict__ A,
-													float4* __restrict__ accum) {
+													float4* __restrict__ accum, const unsigned* __restrict__ counts) {
+	if (batch_overflowed(counts, sc.maxDepth)) return;
 	const int p = blockIdx.x * 256 + threadIdx.x;
 	if (p * 4 >= b.nSamples) return;
 	int x, y, sub;
@@ -1276,7 +1286,8 @@ __global__ __launch_bounds__(256) void k_tonemap(const float4* __restrict__ accu
 
 // Per-sample radiance export (rtx_sample_radiance): out[(y*W+x)*4+sub] = A[j].
 __global__ __launch_bounds__(256) void k_export_samples(DevScene sc, Batch b, const float4* __restrict__ A,
-														float4* __restrict__ out) {
+														float4* __restrict__ out, const unsigned* __restrict__ counts) {
+	if (batch_overflowed(counts, sc.maxDepth)) return;
 	const int j = blockIdx.x * 256 + threadIdx.x;
 	if (j >= b.nSamples) return;
 	int x, y, sub;
@@ -1396,6 +1407,10 @@ struct rtx_scene {
 	int stackNeed = 32;  // deepest interior node: the traversal pushes at most once per interior level
 	int wideStackNeed = 52;  // wide traversal: entries waiting when every child of every node on a path is hit
 	int wideStackCap = 24;   // RTX_WIDE_STACK: 16 or 24
+	// largest number of rays per primary sample seen at each level so far (0: nothing seen yet)
+	double popRatio[17] = {0};
+	bool haveHistory = false;
+	bool worstCaseQueues = false;  // RTX_WORST_CASE_QUEUES=1: never size queues from history
 	bool wideOk = false;     // the tree satisfies what k_trace_wide relies on
 	bool forceBinary = false;  // RTX_TRACE_BINARY=1: binary-tree kernel only (for comparisons)
 	uint32_t numWide = 0;
@@ -1544,20 +1559,9 @@ int ensure_ready(rtx_scene* s, bool needCamera) {
 	return RTX_OK;
 }
 
-// Worst-case queue bytes per primary sample: every node spawns the maximum number of
-// children at every level.  Persistent per node: A (16) + B (16) + C (16); transient, two
-// ping-pong sets sized for the widest level: origin (16) + direction (16) + hit (16).
+// Queue bytes.  Persistent per path node: A (16) + B (16) + C (16); transient, two ping-pong sets sized
+// for the widest level: origin (16) + direction (16) + hit (16).
 constexpr size_t NODE_BYTES = 48, RAY_BYTES = 48;
-
-double worst_bytes_per_sample(const rtx_scene* s) {
-	double bmax = (double)std::max(s->nSpec + s->nDiff, s->nSpec + 1);
-	double sum = 0.0, pw = 1.0;
-	for (int d = 0; d <= s->maxDepth; ++d) {
-		sum += pw;
-		if (d < s->maxDepth) pw *= bmax;
-	}
-	return sum * NODE_BYTES + pw * (2.0 * RAY_BYTES + 4.0);
-}
 
 struct EventScope {
 	rtx_scene* s;
@@ -1710,45 +1714,69 @@ struct Bump {
 	}
 };
 
-// mode: 0 = accumulate, 1 = export per-sample radiance to dOut (float4 per sample),
-//       2 = primary hits only (hitMode 0 culled / 1 exhaustive) exported to dIds/dTab.
-int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* dOut, int* dIds, float* dTab) {
-	const DevScene d = make_dev_scene(s);
-	const int slots = tile_slots(s);
-	const long long totalBlocks = (long long)slots * BLOCKS_PER_TILE;
-	if (totalBlocks == 0) return RTX_OK;
-	const int levels = (mode == 2) ? 0 : s->maxDepth;
-	const int bmax = std::max(s->nSpec + s->nDiff, s->nSpec + 1);
+// Rays per primary sample each level's queue is sized for.  Worst case: every node spawns its maximum at every
+// level.  With history: 1.3 times the most seen so far plus a little, capped by the worst case; a batch that
+// outgrows that is detected on the device, left out of the image and rendered again with worst-case queues.
+void level_ratios(const rtx_scene* s, bool useHistory, int levels, double* r) {
+	const double bmax = (double)std::max(s->nSpec + s->nDiff, s->nSpec + 1);
+	double worst = 1.0;
+	for (int lv = 0; lv <= levels; ++lv) {
+		r[lv] = (useHistory && lv > 0) ? std::min(worst, s->popRatio[lv] * 1.3 + 1.0 / 64.0) : worst;
+		worst *= bmax;
+	}
+}
 
-	// batch size from the arena budget
-	double perSample = (mode == 2) ? (double)(NODE_BYTES + 2 * RAY_BYTES + 4) : worst_bytes_per_sample(s);
+struct RenderTarget {
+	int mode;      // 0 = accumulate, 1 = export per-sample radiance to dOut, 2 = primary hits to dIds/dTab
+	int hitMode;   // mode 2: 0 culled / 1 exhaustive
+	float4* dOut;
+	int* dIds;
+	float* dTab;
+};
+
+// Renders the 4x4-pixel blocks [gBegin, gEnd) of this scene's tile share in as few pixel batches as the arena allows.
+int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTarget& tg, long long gBegin, long long gEnd,
+				 bool useHistory) {
+	const int mode = tg.mode;
+	const int levels = (mode == 2) ? 0 : s->maxDepth;
+	double ratio[MAX_DEPTH + 2];
+	level_ratios(s, useHistory, levels, ratio);
+	double sumRatio = 0.0, maxRatio = 0.0;
+	for (int lv = 0; lv <= levels; ++lv) {
+		sumRatio += ratio[lv];
+		maxRatio = std::max(maxRatio, ratio[lv]);
+	}
+	// per sample: A, B, C of every level; two ping-pong ray sets and the set-aside list sized for the widest level
+	const double perSample = (mode == 2) ? (double)(NODE_BYTES + 2 * RAY_BYTES + 4) : sumRatio * NODE_BYTES + maxRatio * (2.0 * RAY_BYTES + 4.0);
+	const double fixedBytes = (double)(MAX_DEPTH + 8) * 4096 + (double)(levels + 1) * 1024.0 * NODE_BYTES + 1024.0 * (2.0 * RAY_BYTES + 4.0) + 65536.0;
+	const long long totalBlocks = gEnd - gBegin;
+
 	size_t freeB = 0, totalB = 0;
 	HIPCHK(hipMemGetInfo(&freeB, &totalB));
-	// Default budget: 60 % of what is free, at most 64 GiB.  Queues are sized for the worst case (every node
-	// spawning its maximum at every level), so deep recursion is split into several pixel batches; each batch
-	// costs one synchronisation plus, per level, the latency of its longest ray.
+	// Default budget: 60 % of what is free, at most 64 GiB.  Each batch costs one synchronisation plus, per
+	// level, the latency of its longest ray, so bigger batches are better; allocating and mapping hundreds of GB
+	// costs seconds, so the arena is not grown beyond that.
 	size_t budget = s->arenaLimit ? (size_t)s->arenaLimit
 								  : std::min<size_t>((size_t)((double)(freeB + s->arena.n) * 0.6), (size_t)64 << 30);
-	double needAll = perSample * (double)totalBlocks * SAMPLES_PER_BLOCK + (double)(MAX_DEPTH + 8) * 4096;
+	const double needAll = perSample * (double)totalBlocks * SAMPLES_PER_BLOCK + fixedBytes;
 	size_t want = (size_t)std::min((double)budget, needAll);
-	// an arena that is nearly as big as wanted is used as it is rather than reallocated
-	if (s->arena.n && s->arena.n < want && (double)s->arena.n >= 0.9 * (double)want) want = s->arena.n;
-	long long blocksPerBatch = (long long)(((double)want - (double)(MAX_DEPTH + 8) * 4096) / (perSample * SAMPLES_PER_BLOCK));
+	// an arena that is at least nearly as big as wanted is used as it is rather than reallocated
+	if (s->arena.n && (double)s->arena.n >= 0.9 * (double)want) want = std::max(want, s->arena.n);
+	if (s->arenaLimit && want > (size_t)s->arenaLimit) want = (size_t)s->arenaLimit;
+	long long blocksPerBatch = (long long)(((double)want - fixedBytes) / (perSample * SAMPLES_PER_BLOCK));
 	if (blocksPerBatch < 1) {
 		blocksPerBatch = 1;
-		want = (size_t)(perSample * SAMPLES_PER_BLOCK) + (MAX_DEPTH + 8) * 4096;
+		want = (size_t)(perSample * SAMPLES_PER_BLOCK + fixedBytes);
 	}
 	if (blocksPerBatch > totalBlocks) blocksPerBatch = totalBlocks;
-	// keep sample indices inside int32
-	const long long maxBlocksInt = (long long)(0x7FFFFF00ll / SAMPLES_PER_BLOCK);
-	long long widest = 1;
-	for (int i = 0; i < levels; ++i) widest *= bmax;
-	if (blocksPerBatch * widest > maxBlocksInt) blocksPerBatch = std::max<long long>(1, maxBlocksInt / widest);
+	// keep ray indices inside int32
+	const long long maxBlocksInt = (long long)(0x7FFFF000ll / SAMPLES_PER_BLOCK);
+	if ((double)blocksPerBatch * maxRatio > (double)maxBlocksInt) blocksPerBatch = std::max<long long>(1, (long long)((double)maxBlocksInt / maxRatio));
 	int rc = ensure_arena(s, want);
 	if (rc) return rc;
 
-	for (long long g0 = 0; g0 < totalBlocks; g0 += blocksPerBatch) {
-		const long long nb = std::min(blocksPerBatch, totalBlocks - g0);
+	for (long long g0 = gBegin; g0 < gEnd; g0 += blocksPerBatch) {
+		const long long nb = std::min(blocksPerBatch, gEnd - g0);
 		Batch b;
 		b.g0 = (int)g0;
 		b.nSamples = (int)(nb * SAMPLES_PER_BLOCK);
@@ -1756,9 +1784,21 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 		b.tileStride = s->tileStride;
 		s->stats.chunks++;
 
-		// arena carve-up: transient ray sets at the top, node arrays bump-allocated from the bottom
+		// capacities of the levels of this batch
+		size_t cap[MAX_DEPTH + 2];
 		size_t widestCap = (size_t)b.nSamples;
-		for (int i = 0; i < levels; ++i) widestCap *= (size_t)bmax;
+		{
+			size_t worst = (size_t)b.nSamples;
+			const size_t bmax = (size_t)std::max(s->nSpec + s->nDiff, s->nSpec + 1);
+			for (int lv = 0; lv <= levels; ++lv) {
+				cap[lv] = lv == 0 ? worst : std::min(worst, (size_t)std::ceil((double)b.nSamples * ratio[lv]) + 1024);
+				widestCap = std::max(widestCap, cap[lv]);
+				worst *= bmax;
+			}
+			cap[levels + 1] = 0;
+		}
+
+		// arena carve-up: transient ray sets at the top, node arrays bump-allocated from the bottom
 		const size_t setBytes = ((widestCap * 16 + 255) & ~(size_t)255);
 		const size_t listBytes = ((widestCap * 4 + 255) & ~(size_t)255);
 		Bump bump{s->arena.p, s->arena.n, 0, s->arena.n};
@@ -1779,9 +1819,9 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 		if (rc) return rc;
 
 		if (mode == 2) {
-			rc = launch_trace(s, d, false, hitMode == 1, rayO[0], rayD[0], hit[0], b.nSamples, s->dCounts.p, unsafeList);
+			rc = launch_trace(s, d, false, tg.hitMode == 1, rayO[0], rayD[0], hit[0], b.nSamples, s->dCounts.p, unsafeList);
 			if (rc) return rc;
-			hipLaunchKernelGGL(k_export_hits, dim3((b.nSamples + 255) / 256), dim3(256), 0, s->stream, d, b, hit[0], dIds, dTab);
+			hipLaunchKernelGGL(k_export_hits, dim3((b.nSamples + 255) / 256), dim3(256), 0, s->stream, d, b, hit[0], tg.dIds, tg.dTab);
 			HIPCHK(hipGetLastError());
 			HIPCHK(hipStreamSynchronize(s->stream));
 			continue;
@@ -1789,15 +1829,12 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 
 		// Every level is enqueued at once: a level's queue length stays on the device (slot 0 of its counter
 		// block, written by the shade kernel of the level above), arrays are carved at the level's capacity
-		// and grids sized for it.  The host reads the counters once, after the batch.
+		// and grids are fixed.  The host reads the counters once, after the batch.
 		float4* A[MAX_DEPTH + 1];
 		int4* B[MAX_DEPTH + 1];
 		float4* C[MAX_DEPTH + 1];
-		size_t cap[MAX_DEPTH + 2];
-		cap[0] = (size_t)b.nSamples;
 		for (int lv = 0; lv <= s->maxDepth; ++lv) {
 			const size_t n = cap[lv];
-			cap[lv + 1] = std::min(n * (size_t)bmax, widestCap);
 			A[lv] = (float4*)bump.take(n * 16);
 			B[lv] = (int4*)bump.take(n * 16);
 			C[lv] = (float4*)bump.take(n * 16);
@@ -1831,31 +1868,52 @@ int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* 
 		}
 		const int npix = b.nSamples / 4;
 		if (mode == 0)
-			hipLaunchKernelGGL(k_accumulate, dim3((npix + 255) / 256), dim3(256), 0, s->stream, d, b, A[0], s->dAccum);
+			hipLaunchKernelGGL(k_accumulate, dim3((npix + 255) / 256), dim3(256), 0, s->stream, d, b, A[0], s->dAccum, s->dCounts.p);
 		else
-			hipLaunchKernelGGL(k_export_samples, dim3((b.nSamples + 255) / 256), dim3(256), 0, s->stream, d, b, A[0], dOut);
+			hipLaunchKernelGGL(k_export_samples, dim3((b.nSamples + 255) / 256), dim3(256), 0, s->stream, d, b, A[0], tg.dOut, s->dCounts.p);
 		HIPCHK(hipGetLastError());
 		rc = end_event(s, ev);
 		if (rc) return rc;
 		HIPCHK(hipMemcpyAsync(s->hCounts, s->dCounts.p, (MAX_DEPTH + 2) * CNT_STRIDE * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
 		HIPCHK(hipStreamSynchronize(s->stream));
-		{
-			uint64_t n = (uint64_t)b.nSamples;
-			for (int lv = 0; lv <= s->maxDepth; ++lv) {
-				const unsigned* hc = s->hCounts + (size_t)(lv + 1) * CNT_STRIDE;
-				if (hc[4]) return fail(RTX_ERR_MEMORY, "child queue overflow (internal sizing error)");
-				s->stats.rays_per_level[lv] += n - hc[1];
-				s->stats.rays += n - hc[1];
-				s->stats.shaded_hits += hc[2];
-				s->stats.texture_fetches += hc[3];
-				n = hc[0];
-			}
-		}
 		rc = harvest_events(s);
 		if (rc) return rc;
+
+		bool overflow = false;
+		for (int lv = 0; lv <= s->maxDepth; ++lv) overflow = overflow || s->hCounts[(size_t)(lv + 1) * CNT_STRIDE + 4] != 0;
+		// what the levels asked for, whether or not it fitted (the cursor runs on past the capacity)
+		for (int lv = 1; lv <= s->maxDepth; ++lv)
+			s->popRatio[lv] = std::max(s->popRatio[lv], (double)s->hCounts[(size_t)lv * CNT_STRIDE] / (double)b.nSamples);
+		if (overflow) {
+			if (!useHistory) return fail(RTX_ERR_MEMORY, "child queue overflow (internal sizing error)");
+			// nothing of this batch was stored: once more, with queues that cannot overflow
+			s->stats.chunks--;
+			s->stats.queue_retries++;
+			rc = render_range(s, d, frame, tg, g0, g0 + nb, false);
+			if (rc) return rc;
+			continue;
+		}
+		s->haveHistory = true;
+		uint64_t n = (uint64_t)b.nSamples;
+		for (int lv = 0; lv <= s->maxDepth; ++lv) {
+			const unsigned* hc = s->hCounts + (size_t)(lv + 1) * CNT_STRIDE;
+			s->stats.rays_per_level[lv] += n - hc[1];
+			s->stats.rays += n - hc[1];
+			s->stats.shaded_hits += hc[2];
+			s->stats.texture_fetches += hc[3];
+			n = hc[0];
+		}
 	}
 	HIPCHK(hipStreamSynchronize(s->stream));
 	return harvest_events(s);
+}
+
+int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* dOut, int* dIds, float* dTab) {
+	const DevScene d = make_dev_scene(s);
+	const long long totalBlocks = (long long)tile_slots(s) * BLOCKS_PER_TILE;
+	if (totalBlocks == 0) return RTX_OK;
+	const RenderTarget tg{mode, hitMode, dOut, dIds, dTab};
+	return render_range(s, d, frame, tg, 0, totalBlocks, s->haveHistory && !s->worstCaseQueues);
 }
 
 int finish_stats(rtx_scene* s) {
@@ -1908,6 +1966,7 @@ RTX_API int rtx_scene_create(rtx_scene** out, int device) {
 	if (const char* e = std::getenv("RTX_TRACE_TRI_BATCH")) s->traceTriBatch = std::max(1, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_TRACE_BLOCKS_PER_CU")) s->traceBlocksPerCU = std::max(1, std::atoi(e));
 	if (const char* e = std::getenv("RTX_TRACE_BINARY")) s->forceBinary = std::atoi(e) != 0;
+	if (const char* e = std::getenv("RTX_WORST_CASE_QUEUES")) s->worstCaseQueues = std::atoi(e) != 0;
 	if (const char* e = std::getenv("RTX_WIDE_STACK")) s->wideStackCap = std::max(16, std::min(24, std::atoi(e)));
 	std::memset(&s->stats, 0, sizeof(s->stats));
 	*out = s;
@@ -1947,6 +2006,8 @@ RTX_API int rtx_scene_set_params(rtx_scene* s, int width, int height, int max_de
 	for (int i = 0; i < 3; ++i) s->bg[i] = background_rgb[i];
 	s->seed = seed;
 	s->haveParams = true;
+	s->haveHistory = false;
+	std::fill(s->popRatio, s->popRatio + 17, 0.0);
 	return RTX_OK;
 }
 
@@ -1983,6 +2044,8 @@ RTX_API int rtx_scene_set_triangles(rtx_scene* s, const void* triangles, uint32_
 	s->sceneAbsMax = amax;
 	s->haveTris = true;
 	s->haveBvh = false;
+	s->haveHistory = false;
+	std::fill(s->popRatio, s->popRatio + 17, 0.0);
 	return RTX_OK;
 }
 

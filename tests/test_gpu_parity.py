@@ -258,6 +258,44 @@ def test_external_accumulator_and_resume(libs):
     assert_bits_equal(want, rt.accum(), "resume")
 
 
+def test_queue_history_overflow_is_rendered_again(libs):
+    """Queues are sized from the ray populations of earlier frames.  History taken from one tile of sky makes
+    the queues of the full image far too small: the device notices, stores nothing of such a batch, and the
+    host renders it again with worst-case queues.  The image must equal the one of a scene without history."""
+    sc = scenes.mixed_scene(seed=9, width=256, height=192)
+    nodes = api.build_bvh(sc.tris)
+    fresh = api.RayTracer(0)
+    fresh.load_scene(sc, nodes)
+    fresh.reset()
+    fresh.render(1, 2)
+    want = fresh.accum()
+    assert fresh.stats()["queue_retries"] == 0
+    rt = api.RayTracer(0)
+    rt.load_scene(sc, nodes)
+    pops = []
+    for t in range(12):                      # find the emptiest tile: its rays die at level 0
+        rt.set_tiles(t, 1, 1)
+        rt.reset()
+        rt.render(1, 1)
+        pops.append(rt.stats()["rays"])
+    rt2 = api.RayTracer(0)
+    rt2.load_scene(sc, nodes)
+    rt2.set_tiles(int(np.argmin(pops)), 1, 1)
+    rt2.render(1, 1)                         # the only history this scene has
+    rt2.set_tiles(0, 1, -1)
+    rt2.reset()
+    rt2.render(1, 2)
+    st = rt2.stats()
+    assert st["queue_retries"] >= 1, (st["queue_retries"], pops)
+    assert_bits_equal(want, rt2.accum(), "after overflow and retry")
+    assert st["rays"] == fresh.stats()["rays"]
+    # with honest history the next frames fit without retries
+    rt2.render(3, 2)
+    assert rt2.stats()["queue_retries"] == 0
+    fresh.render(3, 2)
+    assert_bits_equal(fresh.accum(), rt2.accum(), "frames 3-4")
+
+
 def test_device_tonemap_equals_host(libs):
     """rtx_tonemap_read (table search on the device) gives the bytes of the host tone map of
     src/RayTracer.cpp:248-257, on rendered accumulators and on synthetic ones with the awkward values."""
