@@ -38,7 +38,7 @@ def _hipcc():
 
 def build_hip(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "rtx_wide.h"), os.path.join(PKG, "..", "include", "rtx.h")]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("rtx_wide.h", "rtx_dev_common.h", "rtx_dev_trace.h", "rtx_dev_shade.h")] + [os.path.join(PKG, "..", "include", "rtx.h")]
     if not force and _newer(HIP_SO, deps):
         return HIP_SO
     cmd = [_hipcc()] + HIP_FLAGS + srcs + ["-o", HIP_SO]

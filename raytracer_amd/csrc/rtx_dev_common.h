@@ -1,0 +1,169 @@
+// Device-side scene description, the counter-based random numbers, texture and sky look-ups, and the mapping of
+// queue slots to pixels shared by the kernels of rtx_hip.hip (included there; not a stand-alone header).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Device-side scene description, passed to kernels by value.
+
+constexpr int TILE = 64;            // image tile edge in pixels (sharding granule)
+constexpr int BLK = 4;              // a wave covers a BLK x BLK pixel block x 4 sub-samples
+constexpr int BLOCKS_PER_TILE = (TILE / BLK) * (TILE / BLK);
+constexpr int SAMPLES_PER_BLOCK = BLK * BLK * 4;  // 64 = one wave
+constexpr int TRACE_THREADS = 256;
+
+enum NodeKind : int { KIND_LEAF = 0, KIND_METAL = 1, KIND_TRANSP = 2, KIND_DIEL = 3 };
+constexpr int FLAG_TEX = 0x100;
+constexpr int FLAG_TIR = 0x200;
+
+constexpr int TRI_EMIT = 1, TRI_METAL = 2, TRI_TRANSP = 4;
+
+struct DevScene {
+	const float4* pairs;     // 4 x float4 per child pair: Lmin|codeL, Lmax|-, Rmin|codeR, Rmax|-
+	const float4* wide;      // 4 x float4 per node of the 4-wide quantised collapse of the tree
+	const float4* triHit;    // 4 x float4 per triangle in candidate-rank order: n, v0, v1, v2, index
+	const float4* triShade;  // 4 x float4 per triangle in candidate-rank order: n0 r | n1 g | n2 b | rough ior tex flags
+	const float4* triUv;     // 2 x float4 per triangle: uv0 uv1 | uv2 - -   (read for textured hits only)
+	const uint8_t* texels;
+	const int4* texDesc;     // byte offset, width, height
+	const float* cosT;
+	const float* sinT;
+	const float* gammaT;
+	float4 camO, camLUC, camRS, camDS;
+	float4 bg;
+	int width, height, maxDepth, nDiff, nSpec;
+	int hasSky;
+	float skyBrightness;
+	int skyTex[6];
+	uint32_t seedKey;
+	float sceneAbsMax;
+	int tilesX;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Small device helpers.  dot4 is Eigen's reduction order with the (zero) w lane kept as "+ 0.0f".
+
+__device__ __forceinline__ float dot3w(float ax, float ay, float az, float bx, float by, float bz) {
+	return (ax * bx + az * bz) + (ay * by + 0.0f);
+}
+
+__device__ __forceinline__ uint32_t rt_mix(uint32_t h, uint32_t v) {
+	h = (h + 0x7F4A7C15u) ^ (v * 0x9E3779B1u);
+	h ^= h >> 16;
+	h *= 0x85EBCA6Bu;
+	h ^= h >> 13;
+	h *= 0xC2B2AE35u;
+	h ^= h >> 16;
+	return h;
+}
+__device__ __forceinline__ uint32_t rt_child_key(uint32_t key, uint32_t ordinal) { return rt_mix(key, 1u + ordinal); }
+__device__ __forceinline__ uint32_t rt_draw(uint32_t key, uint32_t lobe, uint32_t k, uint32_t dim) {
+	return rt_mix(key, 0x80000000u | (lobe << 20) | (k << 1) | dim);
+}
+
+__device__ __forceinline__ float clamp01(float u) {
+	u = (u >= 0.0f) ? u : 0.0f;
+	u = (u <= 1.0f) ? u : 1.0f;
+	return u;
+}
+
+// Texture::sampleTexture (src/Texture.cpp:41-53) with clamped coordinates and the
+// powf(c/255, 2.2) decode taken from the host-computed table.
+__device__ __forceinline__ float3 tex_fetch(const DevScene& sc, int id, float u, float v) {
+	int4 d = sc.texDesc[id];
+	u = clamp01(u);
+	v = clamp01(v);
+	float uMax = (float)(d.y - 1);
+	float vMax = (float)(d.z - 1);
+	int sx = (int)roundf(u * uMax);
+	int sy = (int)roundf(v * vMax);
+	const uint8_t* c = sc.texels + (size_t)(uint32_t)d.x + ((size_t)sy * (size_t)d.y + (size_t)sx) * 3;
+	return make_float3(sc.gammaT[c[0]], sc.gammaT[c[1]], sc.gammaT[c[2]]);
+}
+
+// Skybox::sampleBackground (src/Skybox.cpp:32-84).
+__device__ float3 sky_fetch(const DevScene& sc, float dx, float dy, float dz) {
+	for (int i = 0; i < 6; ++i) {
+		float divisor, u, v;
+		float px, py, pz;
+		switch (i) {
+		case 0:
+			divisor = dz;
+			px = dx / divisor; py = dy / divisor;
+			u = (1.0f - px) * 0.5f;
+			v = (1.0f + py) * 0.5f;
+			break;
+		case 1:
+			divisor = -dz;
+			px = dx / divisor; py = dy / divisor;
+			u = (1.0f + px) * 0.5f;
+			v = (1.0f + py) * 0.5f;
+			break;
+		case 2:
+			divisor = -dx;
+			pz = dz / divisor; py = dy / divisor;
+			u = (1.0f - pz) * 0.5f;
+			v = (1.0f + py) * 0.5f;
+			break;
+		case 3:
+			divisor = dx;
+			pz = dz / divisor; py = dy / divisor;
+			u = (pz + 1.0f) * 0.5f;
+			v = (py + 1.0f) * 0.5f;
+			break;
+		case 4:
+			divisor = dy;
+			px = dx / divisor; pz = dz / divisor;
+			u = (px + 1.0f) * 0.5f;
+			v = (pz + 1.0f) * 0.5f;
+			break;
+		default:
+			divisor = -dy;
+			px = dx / divisor; pz = dz / divisor;
+			u = (px + 1.0f) * 0.5f;
+			v = (pz - 1.0f) * 0.5f;
+			break;
+		}
+		if (divisor < 0.0f || u < 0.0f || v < 0.0f || u > 1.0f || v > 1.0f) continue;
+		float3 c = tex_fetch(sc, sc.skyTex[i], u, v);
+		return make_float3(c.x * sc.skyBrightness, c.y * sc.skyBrightness, c.z * sc.skyBrightness);
+	}
+	return make_float3(0.0f, 0.0f, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Level-0 sample order.  Sample j of a batch that starts at pixel block g0:
+//   block g = g0 + j/64 -> (tile slot, block in tile); lane = j%64 -> (pixel in block, sub-sample).
+// A wave therefore holds the 4 sub-samples of a 4x4 pixel block, which keeps primary rays of
+// one wave spatially adjacent.  Tiles are taken from the arithmetic list first + k*stride.
+
+struct Batch {
+	int g0;          // first pixel block (global over the scene's tile list)
+	int nSamples;    // (number of blocks) * 64
+	int tileFirst, tileStride;
+};
+
+__device__ __forceinline__ bool sample_to_pixel(const DevScene& sc, const Batch& b, int j, int& x, int& y, int& sub) {
+	int g = b.g0 + (j >> 6);
+	int lane = j & 63;
+	int slot = g / BLOCKS_PER_TILE;
+	int blk = g - slot * BLOCKS_PER_TILE;
+	int tile = b.tileFirst + slot * b.tileStride;
+	int ty = tile / sc.tilesX;
+	int tx = tile - ty * sc.tilesX;
+	int by = blk / (TILE / BLK);
+	int bx = blk - by * (TILE / BLK);
+	int pix = lane >> 2;
+	sub = lane & 3;
+	x = tx * TILE + bx * BLK + (pix & 3);
+	y = ty * TILE + by * BLK + (pix >> 2);
+	return x < sc.width && y < sc.height;
+}
+
+}  // namespace

@@ -1,0 +1,503 @@
+// Ray generation, shading, gather, accumulate, tone map and export kernels of rtx_hip.hip (included there).
+#pragma once
+
+#include "rtx_dev_common.h"
+
+namespace {
+
+// Camera::getRay (src/Camera.cpp:37-49) plus the per-sample RNG key.
+__global__ __launch_bounds__(256) void k_raygen(DevScene sc, Batch b, uint32_t frame, float4* __restrict__ rayO,
+												float4* __restrict__ rayD) {
+	int j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= b.nSamples) return;
+	int x, y, sub;
+	bool valid = sample_to_pixel(sc, b, j, x, y, sub);
+	if (!valid) {
+		rayO[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		rayD[j] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);  // w = 1 marks a dead slot
+		return;
+	}
+	const float xo = (sub & 1) ? 0.25f : -0.25f;
+	const float yo = (sub & 2) ? 0.25f : -0.25f;
+	float xTemp = (float)x + xo;
+	float yTemp = (float)y + yo;
+	float dx = (sc.camLUC.x + xTemp * sc.camRS.x) + yTemp * sc.camDS.x;
+	float dy = (sc.camLUC.y + xTemp * sc.camRS.y) + yTemp * sc.camDS.y;
+	float dz = (sc.camLUC.z + xTemp * sc.camRS.z) + yTemp * sc.camDS.z;
+	uint32_t sample = ((uint32_t)y * (uint32_t)sc.width + (uint32_t)x) * 4u + (uint32_t)sub;
+	uint32_t key = rt_mix(rt_mix(sc.seedKey, frame), sample);
+	rayO[j] = make_float4(sc.camO.x, sc.camO.y, sc.camO.z, __uint_as_float(key));
+	rayD[j] = make_float4(dx, dy, dz, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shade.  One thread per ray of level `level`.  Writes the path-node record of this ray:
+//   A[j]  leaf: its radiance.   interior: triangle colour (replaced by the node's radiance in k_gather)
+//   B[j]  (first child slot, kind | flags, scalar as float bits, -)   scalar = |n.d| (dielectric) or
+//         the refracted proportion (transparent)
+//   C[j]  texel of a textured dielectric
+// and appends the node's child rays to the next level's queue.  cnt[0] receives the queue
+// length, cnt[1] dead slots (refraction under total internal reflection), cnt[2] shaded hits,
+// cnt[3] texel fetches.
+
+__device__ __forceinline__ void scatter_offset(const DevScene& sc, uint32_t key, uint32_t lobe, uint32_t k, float& ox,
+											   float& oy, float& oz) {
+	uint32_t phi = rt_draw(key, lobe, k, 0) & 0x1FFu;
+	uint32_t theta = (rt_draw(key, lobe, k, 1) & 0x1FFu) >> 1;
+	float cp = sc.cosT[phi], sp = sc.sinT[phi], ct = sc.cosT[theta], st = sc.sinT[theta];
+	// horizontal * sin(theta) + cos(theta) * UnitZ, lane by lane (src/Triangle.cpp:107-113)
+	ox = cp * st + ct * 0.0f;
+	oy = sp * st + ct * 0.0f;
+	oz = 0.0f * st + ct * 1.0f;
+}
+
+constexpr int SHADE_THREADS = 1024;  // 16 waves share one queue-tail atomic
+
+__global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level, const float4* __restrict__ rayO,
+											   const float4* __restrict__ rayD, const float4* __restrict__ hits, int n,
+											   float4* __restrict__ A, int4* __restrict__ B, float4* __restrict__ C,
+											   float4* __restrict__ nRayO, float4* __restrict__ nRayD,
+											   unsigned* __restrict__ cnt, unsigned nextCap, const unsigned* __restrict__ nDev) {
+	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
+	__shared__ unsigned s_tot[SHADE_THREADS / 64];
+	__shared__ unsigned s_base[SHADE_THREADS / 64];
+	__shared__ unsigned s_stat[3][SHADE_THREADS / 64];
+	// The grid does not grow with the queue: a block walks over it in steps of the grid's width (every thread
+	// of a block makes the same number of rounds, so the barriers below are uniform).
+	for (long long base = (long long)blockIdx.x * SHADE_THREADS; base < n; base += (long long)gridDim.x * SHADE_THREADS) {
+		const int j = (int)base + (int)threadIdx.x;
+		const int S = sc.nSpec, Dn = sc.nDiff;
+		int kind = KIND_LEAF;
+		int flags = 0;
+		int nchild = 0;
+		float3 val = make_float3(0.0f, 0.0f, 0.0f);
+		float scalar = 0.0f;
+		float3 texel = make_float3(0.0f, 0.0f, 0.0f);
+		// state needed after the allocation
+		float hx = 0, hy = 0, hz = 0, nx = 0, ny = 0, nz = 0, dx = 0, dy = 0, dz = 0, rough = 0, ior = 1;
+		uint32_t key = 0;
+		unsigned dead = 0, shaded = 0, fetches = 0;
+		const bool active = j < n;
+		if (active) {
+			float4 O = rayO[j];
+			float4 D = rayD[j];
+			float4 H = hits[j];
+			int rank = __float_as_int(H.x);
+			key = __float_as_uint(O.w);
+			dx = D.x; dy = D.y; dz = D.z;
+			if (rank == -2) {
+				dead = 1;
+			}
+			else if (rank == -1) {
+				if (sc.hasSky) {
+					val = sky_fetch(sc, dx, dy, dz);
+					fetches = 1;
+				}
+				else
+					val = make_float3(sc.bg.x, sc.bg.y, sc.bg.z);
+			}
+			else if (level < sc.maxDepth) {
+				// (at level == maxDepth every hit returns zero, src/RayTracer.cpp:170; the any-hit
+				//  traversal reports such hits with rank 0, which is never dereferenced)
+				// one aligned 64-byte record serves every hit; the texture coordinates live apart
+				const float4* T = sc.triShade + (size_t)rank * 4;
+				float4 s0 = T[0], s1 = T[1], s2 = T[2], s3 = T[3];
+				const float t = H.y, alpha = H.z, beta = H.w;
+				const int triFlags = __float_as_int(s3.w);
+				const int texId = __float_as_int(s3.z);
+				hx = O.x + t * dx;
+				hy = O.y + t * dy;
+				hz = O.z + t * dz;
+				float g = 1.0f - (alpha + beta);
+				nx = (alpha * s0.x + beta * s1.x) + g * s2.x;
+				ny = (alpha * s0.y + beta * s1.y) + g * s2.y;
+				nz = (alpha * s0.z + beta * s1.z) + g * s2.z;
+				float z = dot3w(nx, ny, nz, nx, ny, nz);
+				if (z > 0.0f) {
+					float len = sqrtf(z);
+					nx = nx / len;
+					ny = ny / len;
+					nz = nz / len;
+				}
+				float cosine = dot3w(nx, ny, nz, dx, dy, dz);
+				const bool transp = (triFlags & TRI_TRANSP) != 0;
+				if (!transp && cosine >= 0.0f) {
+					// back side: zero
+				}
+				else if (triFlags & TRI_EMIT) {
+					val = make_float3(s0.w, s1.w, s2.w);
+				}
+				else {
+					shaded = 1;
+					val = make_float3(s0.w, s1.w, s2.w);  // colour, consumed by k_gather
+					rough = s3.x;
+					ior = s3.y;
+					if (triFlags & TRI_METAL) {
+						kind = KIND_METAL;
+						nchild = S;
+					}
+					else if (transp) {
+						kind = KIND_TRANSP;
+						nchild = S + 1;
+					}
+					else {
+						kind = KIND_DIEL;
+						nchild = S + Dn;
+						scalar = fabsf(cosine);
+						if (texId >= 0) {
+							flags |= FLAG_TEX;
+							const float4 u01 = sc.triUv[(size_t)rank * 2], u2 = sc.triUv[(size_t)rank * 2 + 1];
+							float u = (alpha * u01.x + beta * u01.z) + g * u2.x;
+							float v = (alpha * u01.y + beta * u01.w) + g * u2.y;
+							texel = tex_fetch(sc, texId, u, v);
+							fetches = 1;
+						}
+					}
+				}
+			}
+		}
+
+		// ---- queue slots for the children.  Inside a wave, per-kind ballots + popcounts give each lane its
+		// offset; the 16 wave totals of the block are scanned in LDS and the block claims its range of the
+		// next level's queue with a single atomic (one word takes only ~90 atomics per microsecond, so one
+		// atomic per wave would bound the kernel).
+		const unsigned lane = threadIdx.x & 63;
+		const unsigned wave = threadIdx.x >> 6;
+		const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+		unsigned long long bm = __ballot(kind == KIND_METAL);
+		unsigned long long bt = __ballot(kind == KIND_TRANSP);
+		unsigned long long bd = __ballot(kind == KIND_DIEL);
+		unsigned offset = (unsigned)__popcll(bm & lt) * (unsigned)S + (unsigned)__popcll(bt & lt) * (unsigned)(S + 1) +
+						  (unsigned)__popcll(bd & lt) * (unsigned)(S + Dn);
+		unsigned total = (unsigned)__popcll(bm) * (unsigned)S + (unsigned)__popcll(bt) * (unsigned)(S + 1) +
+						 (unsigned)__popcll(bd) * (unsigned)(S + Dn);
+		unsigned long long bdead = __ballot(dead != 0), bsh = __ballot(shaded != 0), bf = __ballot(fetches != 0);
+		if (lane == 0) {
+			s_tot[wave] = total;
+			s_stat[0][wave] = (unsigned)__popcll(bdead);
+			s_stat[1][wave] = (unsigned)__popcll(bsh);
+			s_stat[2][wave] = (unsigned)__popcll(bf);
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			unsigned run = 0, d = 0, sh = 0, f = 0;
+			for (int w = 0; w < SHADE_THREADS / 64; ++w) {
+				s_base[w] = run;
+				run += s_tot[w];
+				d += s_stat[0][w];
+				sh += s_stat[1][w];
+				f += s_stat[2][w];
+			}
+			unsigned base = run ? atomicAdd(&cnt[0], run) : 0u;
+			for (int w = 0; w < SHADE_THREADS / 64; ++w) s_base[w] += base;
+			if (d) atomicAdd(&cnt[1], d);
+			if (sh) atomicAdd(&cnt[2], sh);
+			if (f) atomicAdd(&cnt[3], f);
+		}
+		__syncthreads();
+		const unsigned childBase = s_base[wave] + offset;
+
+		if (nchild) {
+			if (childBase + (unsigned)nchild > nextCap) {
+				// cannot happen when the host sized the queue for the worst case; drop the subtree
+				kind = KIND_LEAF;
+				val = make_float3(0.0f, 0.0f, 0.0f);
+				nchild = 0;
+				atomicOr(&cnt[4], 1u);
+			}
+		}
+		if (nchild) {
+			// Triangle::specular (src/Triangle.cpp:121-146)
+			float np = dot3w(dx, dy, dz, nx, ny, nz);
+			float k2 = 2.0f * np;
+			float rx = dx - k2 * nx, ry = dy - k2 * ny, rz = dz - k2 * nz;
+			for (int i = 0; i < S; ++i) {
+				float ox, oy, oz;
+				scatter_offset(sc, key, 0, (uint32_t)i, ox, oy, oz);
+				float cx = rx + ox * rough, cy = ry + oy * rough, cz = rz + oz * rough;
+				nRayO[childBase + i] = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)i)));
+				nRayD[childBase + i] = make_float4(cx, cy, cz, 0.0f);
+			}
+			if (kind == KIND_DIEL) {
+				// Triangle::diffuse (src/Triangle.cpp:95-119)
+				bool keep = dot3w(dx, dy, dz, nx, ny, nz) < 0.0f;
+				float tx = keep ? nx : -nx, ty = keep ? ny : -ny, tz = keep ? nz : -nz;
+				for (int i = 0; i < Dn; ++i) {
+					float ox, oy, oz;
+					scatter_offset(sc, key, 1, (uint32_t)i, ox, oy, oz);
+					nRayO[childBase + S + i] = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)(S + i))));
+					nRayD[childBase + S + i] = make_float4(tx + ox, ty + oy, tz + oz, 0.0f);
+				}
+			}
+			else if (kind == KIND_TRANSP) {
+				// Triangle::refract (src/Triangle.cpp:149-179)
+				float dot = dot3w(dx, dy, dz, nx, ny, nz);
+				float indexRatio = dot > 0.0f ? ior : (1.0f / ior);
+				float tx = dot > 0.0f ? -nx : nx, ty = dot > 0.0f ? -ny : ny, tz = dot > 0.0f ? -nz : nz;
+				float cosineTheta = fabsf(dot);
+				float squareSine1 = 1.0f - cosineTheta * cosineTheta;
+				float squareSine2 = (indexRatio * indexRatio) * squareSine1;
+				float4 ro = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)S)));
+				if (squareSine2 > 1.0f) {
+					// total internal reflection: proportion 0, child not traced
+					flags |= FLAG_TIR;
+					scalar = 0.0f;
+					nRayO[childBase + S] = ro;
+					nRayD[childBase + S] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+				}
+				else {
+					float cosine2 = sqrtf(1.0f - squareSine2);
+					float ex = indexRatio * (dx + cosineTheta * tx) - tx * cosine2;
+					float ey = indexRatio * (dy + cosineTheta * ty) - ty * cosine2;
+					float ez = indexRatio * (dz + cosineTheta * tz) - tz * cosine2;
+					float temp = (1.0f - indexRatio) / (1.0f + indexRatio);
+					float r0 = temp * temp;
+					float squareTemp = (1.0f - cosineTheta) * (1.0f - cosineTheta);
+					float pow5 = squareTemp * squareTemp * (1.0f - cosineTheta);
+					float reflectProportion = r0 + (1.0f - r0) * pow5;
+					scalar = 1.0f - reflectProportion;
+					nRayO[childBase + S] = ro;
+					nRayD[childBase + S] = make_float4(ex, ey, ez, 0.0f);
+				}
+			}
+		}
+		if (active) {
+			A[j] = make_float4(val.x, val.y, val.z, 0.0f);
+			B[j] = make_int4((int)childBase, kind | flags, __float_as_int(scalar), 0);
+			if (flags & FLAG_TEX) C[j] = make_float4(texel.x, texel.y, texel.z, 0.0f);
+		}
+		__syncthreads();  // the LDS words are reused by the next round
+	}
+}
+
+// The rays of the last recursion level end their paths whatever they hit: a hit returns zero
+// (src/RayTracer.cpp:170), a miss the sky or the background (:148-152).  Only A is written (B and C of the
+// last level are never read).  Blocks stride over the queue so that each adds its counts once.
+__global__ __launch_bounds__(256) void k_shade_last(DevScene sc, const float4* __restrict__ rayD, const float4* __restrict__ hits,
+													int n, float4* __restrict__ A, unsigned* __restrict__ cnt, const unsigned* __restrict__ nDev) {
+	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
+	unsigned dead = 0, fetches = 0;
+	for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+		const int rank = __float_as_int(hits[j].x);
+		float3 val = make_float3(0.0f, 0.0f, 0.0f);
+		if (rank == -2) dead++;
+		else if (rank == -1) {
+			if (sc.hasSky) {
+				const float4 D = rayD[j];
+				val = sky_fetch(sc, D.x, D.y, D.z);
+				fetches++;
+			}
+			else
+				val = make_float3(sc.bg.x, sc.bg.y, sc.bg.z);
+		}
+		A[j] = make_float4(val.x, val.y, val.z, 0.0f);
+	}
+	for (int off = 32; off > 0; off >>= 1) {
+		dead += __shfl_down(dead, off, 64);
+		fetches += __shfl_down(fetches, off, 64);
+	}
+	if ((threadIdx.x & 63) == 0) {
+		if (dead) atomicAdd(&cnt[1], dead);
+		if (fetches) atomicAdd(&cnt[3], fetches);
+	}
+}
+
+// Combine step of RayTracer::color for the nodes of one level, children read from the next
+// level (src/RayTracer.cpp:177-224).  Sums start from zero and run in child order, scale
+// factors are applied after the sum, exactly as the reference does.
+__global__ __launch_bounds__(256) void k_gather(int S, int Dn, int n, float4* __restrict__ A,
+												const int4* __restrict__ B, const float4* __restrict__ C,
+												const float4* __restrict__ childA, const unsigned* __restrict__ nDev) {
+	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
+	for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+		int4 b = B[j];
+		const int kind = b.y & 0xFF;
+		if (kind == KIND_LEAF) continue;
+		const float4 col = A[j];
+		const float4* ch = childA + (unsigned)b.x;
+		float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+		for (int i = 0; i < S; ++i) {
+			float4 c = ch[i];
+			sx = sx + c.x;
+			sy = sy + c.y;
+			sz = sz + c.z;
+		}
+		const float fS = (float)S;
+		float ox, oy, oz;
+		if (kind == KIND_METAL) {
+			ox = (sx * col.x) / fS;
+			oy = (sy * col.y) / fS;
+			oz = (sz * col.z) / fS;
+		}
+		else if (kind == KIND_TRANSP) {
+			sx = sx / fS;
+			sy = sy / fS;
+			sz = sz / fS;
+			const float rp = __int_as_float(b.z);
+			float4 rc = (b.y & FLAG_TIR) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : ch[S];
+			const float q = 1.0f - rp;
+			ox = rp * rc.x + q * sx;
+			oy = rp * rc.y + q * sy;
+			oz = rp * rc.z + q * sz;
+		}
+		else {
+			const float w = 0.04f / fS;
+			sx = sx * w;
+			sy = sy * w;
+			sz = sz * w;
+			float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+			for (int i = 0; i < Dn; ++i) {
+				float4 c = ch[S + i];
+				dx = dx + c.x;
+				dy = dy + c.y;
+				dz = dz + c.z;
+			}
+			const float fD = (float)Dn;
+			dx = (dx * col.x) / fD;
+			dy = (dy * col.y) / fD;
+			dz = (dz * col.z) / fD;
+			const float ad = __int_as_float(b.z);
+			ox = sx + dx * ad;
+			oy = sy + dy * ad;
+			oz = sz + dz * ad;
+			if (b.y & FLAG_TEX) {
+				float4 tx = C[j];
+				ox = ox * tx.x;
+				oy = oy * tx.y;
+				oz = oz * tx.z;
+			}
+		}
+		A[j] = make_float4(ox, oy, oz, 0.0f);
+	}
+}
+
+// accumulateImg(row,col) += (c0+c1+c2+c3) * 0.25f (src/RayTracer.cpp:242-246).  One thread per pixel.
+// True when some level's child queue was too small for this batch (slot 4 of the counter blocks): the batch's
+// result is then incomplete, is not stored, and the host renders the batch again with worst-case queues.
+__device__ __forceinline__ bool batch_overflowed(const unsigned* __restrict__ counts, int maxDepth) {
+	unsigned f = 0;
+	for (int lv = 1; lv <= maxDepth + 1; ++lv) f |= counts[lv * 8 + 4];
+	return f != 0;
+}
+
+__global__ __launch_bounds__(256) void k_accumulate(DevScene sc, Batch b, const float4* __restrict__ A,
+													float4* __restrict__ accum, const unsigned* __restrict__ counts) {
+	if (batch_overflowed(counts, sc.maxDepth)) return;
+	const int p = blockIdx.x * 256 + threadIdx.x;
+	if (p * 4 >= b.nSamples) return;
+	int x, y, sub;
+	if (!sample_to_pixel(sc, b, p * 4, x, y, sub)) return;
+	float tx = 0.0f, ty = 0.0f, tz = 0.0f;
+	for (int k = 0; k < 4; ++k) {
+		float4 c = A[p * 4 + k];
+		tx = tx + c.x;
+		ty = ty + c.y;
+		tz = tz + c.z;
+	}
+	float4* dst = accum + ((size_t)y * sc.width + x);
+	float4 a = *dst;
+	a.x = a.x + tx * 0.25f;
+	a.y = a.y + ty * 0.25f;
+	a.z = a.z + tz * 0.25f;
+	a.w = a.w + 0.0f * 0.25f;
+	*dst = a;
+}
+
+// out8 = clamp(lroundf(powf(acc / frame, 1 / 2.2f) * 255)) (src/RayTracer.cpp:248-257) as a table search: the
+// bytes of the step function were tabulated with the host's own libm, `bits` are the float bit patterns at
+// which it steps (ascending, bits[0] = 0).  One thread per four pixels = three packed words of output.
+constexpr int TONE_MAX = 1024;
+__global__ __launch_bounds__(256) void k_tonemap(const float4* __restrict__ accum, int npix, float frame,
+												 const unsigned* __restrict__ bits, const unsigned char* __restrict__ values, int n,
+												 unsigned negative, unsigned nan, unsigned char* __restrict__ rgb8) {
+	__shared__ unsigned sBits[TONE_MAX];
+	__shared__ unsigned char sVal[TONE_MAX];
+	for (int i = threadIdx.x; i < n; i += 256) {
+		sBits[i] = bits[i];
+		sVal[i] = values[i];
+	}
+	__syncthreads();
+	const int p0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+	if (p0 >= npix) return;
+	unsigned char out[12];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		float4 a = p0 + k < npix ? accum[p0 + k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		const float ch[3] = {a.x / frame, a.y / frame, a.z / frame};
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			const unsigned b = __float_as_uint(ch[c]);
+			unsigned v;
+			if (ch[c] != ch[c]) v = nan;
+			else if (b >> 31) v = negative;
+			else {
+				int lo = 0, hi = n;  // last i with sBits[i] <= b
+				while (hi - lo > 1) {
+					const int mid = (lo + hi) >> 1;
+					if (sBits[mid] <= b) lo = mid;
+					else hi = mid;
+				}
+				v = sVal[lo];
+			}
+			out[k * 3 + c] = (unsigned char)v;
+		}
+	}
+	if (p0 + 4 <= npix) {
+		unsigned w[3];
+#pragma unroll
+		for (int i = 0; i < 3; ++i)
+			w[i] = (unsigned)out[i * 4] | ((unsigned)out[i * 4 + 1] << 8) | ((unsigned)out[i * 4 + 2] << 16) | ((unsigned)out[i * 4 + 3] << 24);
+		unsigned* dst = (unsigned*)(rgb8 + (size_t)p0 * 3);  // p0 is a multiple of 4: 12-byte stride, 4-byte aligned
+		dst[0] = w[0];
+		dst[1] = w[1];
+		dst[2] = w[2];
+	}
+	else {
+		for (int i = 0; i < (npix - p0) * 3; ++i) rgb8[(size_t)p0 * 3 + i] = out[i];
+	}
+}
+
+// Per-sample radiance export (rtx_sample_radiance): out[(y*W+x)*4+sub] = A[j].
+__global__ __launch_bounds__(256) void k_export_samples(DevScene sc, Batch b, const float4* __restrict__ A,
+														float4* __restrict__ out, const unsigned* __restrict__ counts) {
+	if (batch_overflowed(counts, sc.maxDepth)) return;
+	const int j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= b.nSamples) return;
+	int x, y, sub;
+	if (!sample_to_pixel(sc, b, j, x, y, sub)) return;
+	out[((size_t)y * sc.width + x) * 4 + sub] = A[j];
+}
+
+// Primary-hit export: rank -> reference triangle index.
+__global__ __launch_bounds__(256) void k_export_hits(DevScene sc, Batch b, const float4* __restrict__ hits,
+													 int* __restrict__ ids, float* __restrict__ tab) {
+	const int j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= b.nSamples) return;
+	int x, y, sub;
+	if (!sample_to_pixel(sc, b, j, x, y, sub)) return;
+	float4 h = hits[j];
+	int rank = __float_as_int(h.x);
+	size_t o = ((size_t)y * sc.width + x) * 4 + sub;
+	ids[o] = rank >= 0 ? __float_as_int(sc.triHit[(size_t)rank * 4 + 3].x) : -1;
+	if (tab) {
+		tab[o * 3 + 0] = h.y;
+		tab[o * 3 + 1] = h.z;
+		tab[o * 3 + 2] = h.w;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_export_hits_linear(DevScene sc, int n, const float4* __restrict__ hits,
+															int* __restrict__ ids, float* __restrict__ tab) {
+	const int j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= n) return;
+	float4 h = hits[j];
+	int rank = __float_as_int(h.x);
+	ids[j] = rank >= 0 ? __float_as_int(sc.triHit[(size_t)rank * 4 + 3].x) : -1;
+	if (tab) {
+		tab[(size_t)j * 3 + 0] = h.y;
+		tab[(size_t)j * 3 + 1] = h.z;
+		tab[(size_t)j * 3 + 2] = h.w;
+	}
+}
+
+}  // namespace

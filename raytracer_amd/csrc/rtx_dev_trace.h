@@ -1,0 +1,621 @@
+// Traversal kernels of rtx_hip.hip: Triangle::hit and AABB::hit restated, the binary-tree kernel over the
+// reference's own tree and the 4-wide kernel over the tree of rtx_wide.h (included by rtx_hip.hip).
+#pragma once
+
+#include "rtx_dev_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Traversal.
+
+struct HitState {
+	float t, alpha, beta;
+	int rank;
+};
+
+// Triangle::hit (src/Triangle.cpp:23-93) for plane normal n and vertices v0, v1, v2, folded with the
+// closest-hit rule of src/RayTracer.cpp:145 extended by the candidate-order tie break.
+// Returns true when the triangle was accepted (any-hit callers stop there).
+__device__ __forceinline__ bool tri_test_vals(float nx, float ny, float nz, float v0x, float v0y, float v0z, float v1x,
+											  float v1y, float v1z, float v2x, float v2y, float v2z, int rank, float ox,
+											  float oy, float oz, float dx, float dy, float dz, HitState& best) {
+	float temp = dot3w(nx, ny, nz, v0x - ox, v0y - oy, v0z - oz);
+	float t = temp / dot3w(nx, ny, nz, dx, dy, dz);
+	if (!(t > 0.001f)) return false;
+	if (t > best.t || (t == best.t && rank > best.rank)) return false;
+	float bx = (ox + t * dx) - v2x;
+	float by = (oy + t * dy) - v2y;
+	float bz = (oz + t * dz) - v2z;
+	// rows (a1_i, a2_i, b_i), i = x,y,z with a1 = v0 - v2, a2 = v1 - v2 (src/Triangle.cpp:31-32)
+	float r00 = v0x - v2x, r01 = v1x - v2x, r02 = bx;
+	float r10 = v0y - v2y, r11 = v1y - v2y, r12 = by;
+	float r20 = v0z - v2z, r21 = v1z - v2z, r22 = bz;
+	// first pivot: largest |column 0|, strict >, rows tried in order 0,1,2
+	bool s1 = fabsf(r10) > fabsf(r00);
+	float mx = s1 ? fabsf(r10) : fabsf(r00);
+	bool s2 = fabsf(r20) > mx;
+	float p0 = s2 ? r20 : (s1 ? r10 : r00);
+	float p1 = s2 ? r21 : (s1 ? r11 : r01);
+	float p2 = s2 ? r22 : (s1 ? r12 : r02);
+	bool m1 = s1 && !s2;
+	float a0 = m1 ? r00 : r10, a1 = m1 ? r01 : r11, a2 = m1 ? r02 : r12;  // new row 1
+	float c0 = s2 ? r00 : r20, c1 = s2 ? r01 : r21, c2 = s2 ? r02 : r22;  // new row 2
+	p1 = p1 / p0;
+	p2 = p2 / p0;
+	a1 = __fmaf_rn(-p1, a0, a1);
+	a2 = __fmaf_rn(-p2, a0, a2);
+	c1 = __fmaf_rn(-p1, c0, c1);
+	c2 = __fmaf_rn(-p2, c0, c2);
+	// second pivot
+	bool s3 = fabsf(c1) > fabsf(a1);
+	float e1 = s3 ? c1 : a1;
+	float e2 = s3 ? c2 : a2;
+	e2 = e2 / e1;
+	float alpha = __fmaf_rn(-e2, p1, p2);
+	float beta = e2;
+	bool accept = (0.0f <= alpha) & (alpha <= 1.0f) & (0.0f <= beta) & (beta <= 1.0f) & (alpha + beta <= 1.0f);
+	if (!accept) return false;
+	best.t = t;
+	best.alpha = alpha;
+	best.beta = beta;
+	best.rank = rank;
+	return true;
+}
+
+// The triangle stored at `rank`: q0 = n.xyz v0.x | q1 = v0.yz v1.xy | q2 = v1.z v2.xyz | q3 = id - - -
+__device__ __forceinline__ bool tri_test(const float4* __restrict__ triHit, int rank, float ox, float oy, float oz,
+										 float dx, float dy, float dz, HitState& best) {
+	const float4* T = triHit + (size_t)rank * 4;
+	float4 q0 = T[0], q1 = T[1], q2 = T[2];
+	return tri_test_vals(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, rank, ox, oy, oz, dx, dy,
+						 dz, best);
+}
+
+// Per-ray constants of the slab test.
+struct RaySlab {
+	float ox, oy, oz, ix, iy, iz, mx, my, mz;
+	bool nx, ny, nz;
+};
+
+// AABB::hit (src/BVH.cpp:14-41) for one box, plus the conservative entry/exit bounds used
+// for culling.  The folds over lanes 1 and 2 ignore NaN exactly like the reference's
+// "t0 > tmin ? t0 : tmin"; a NaN in lane 0 makes the reference's final comparison false,
+// i.e. a hit, which the unordered test reproduces.
+__device__ __forceinline__ bool box_test(const RaySlab& r, float4 bmin, float4 bmax, float& te, float& tx) {
+	float t0x = (bmin.x - r.ox) * r.ix, t1x = (bmax.x - r.ox) * r.ix;
+	float t0y = (bmin.y - r.oy) * r.iy, t1y = (bmax.y - r.oy) * r.iy;
+	float t0z = (bmin.z - r.oz) * r.iz, t1z = (bmax.z - r.oz) * r.iz;
+	float nX = r.nx ? t1x : t0x, fX = r.nx ? t0x : t1x;
+	float nY = r.ny ? t1y : t0y, fY = r.ny ? t0y : t1y;
+	float nZ = r.nz ? t1z : t0z, fZ = r.nz ? t0z : t1z;
+	float tmin = fmaxf(fmaxf(nX, nY), nZ);
+	float tmax = fminf(fminf(fX, fY), fZ);
+	bool hit = !(tmax < tmin) || (nX != nX) || (fX != fX);
+	te = fmaxf(fmaxf(nX - r.mx, nY - r.my), nZ - r.mz);
+	tx = fminf(fminf(fX + r.mx, fY + r.my), fZ + r.mz);
+	return hit;
+}
+
+// hits[j] = (rank or -1 / -2 for a dead slot, t, alpha, beta), all as raw bits of a float4.
+// ANYHIT: only "some candidate is accepted" is needed (rays at the last recursion depth,
+// src/RayTracer.cpp:154-171); x = 0 then stands for "hit".
+// EXHAUSTIVE: no culling, i.e. the candidate set of BVH::hit itself.
+//
+// Persistent waves: rays of one queue differ in traversal length by orders of magnitude, so a wave
+// that takes 64 rays and waits for the slowest runs mostly empty.  Here a wave keeps running and, once
+// REFILL or more of its lanes are idle, hands them the next rays of its private chunk of the queue
+// (CHUNK consecutive rays claimed with one atomic on *work, which the host zeroes before the launch).
+// Every wave leaves the loop when the queue is exhausted and its lanes have drained.
+constexpr int TRACE_CHUNK = 256;
+constexpr int TRACE_REFILL = 16;
+
+template <int STACK, bool ANYHIT, bool EXHAUSTIVE, bool STATS>
+__global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const float4* __restrict__ rayO,
+														  const float4* __restrict__ rayD, float4* __restrict__ hits,
+														  int n, unsigned long long* __restrict__ stats,
+														  unsigned* __restrict__ work, int refill, int chunk, int triBatch,
+														  const int* __restrict__ list, const unsigned* __restrict__ listCount,
+														  const unsigned* __restrict__ nDev) {
+	// the queue length may live on the device (written by the previous level's shade kernel); n is then the
+	// capacity of the arrays
+	if (nDev) n = (int)min(*nDev, (unsigned)n);
+	// with a list: the rays to trace are list[0 .. *listCount), the ones the wide traversal set aside
+	if (list) n = (int)*listCount;
+	__shared__ int stk[STACK][TRACE_THREADS];
+	const int tid = threadIdx.x;
+	const unsigned lane = (unsigned)tid & 63u;
+	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+
+	unsigned nodeTests = 0, triTests = 0;
+	// wave-uniform: the chunk this wave is handing out
+	int cnext = 0, cend = 0;
+	bool more = true, firstChunk = true;
+	// per lane: the ray in flight (cur < 0: none)
+	int j = -1, cur = -1, sp = 0;
+	RaySlab r;
+	r.ox = r.oy = r.oz = r.ix = r.iy = r.iz = r.mx = r.my = r.mz = 0.0f;
+	r.nx = r.ny = r.nz = false;
+	float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+	HitState best;
+	best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
+	bool found = false;
+
+	// Leaf children are not intersected where they are found: a lane parks them (at most two, the two
+	// children of one pair) and waits.  Once triBatch lanes are parked, or nobody can traverse any more,
+	// the wave runs the triangle code once for all of them.  The address path issues one vector-memory
+	// instruction per ~22 clocks per CU however few lanes it serves, so four loads for one or two lanes
+	// per step would cost as much as the box loads of the whole wave.
+	bool busy = false;
+	int pend0 = -1, pend1 = -1;
+	for (;;) {
+		const unsigned long long idle = __ballot(!busy);
+		const int nidle = __popcll(idle);
+		if (more && nidle >= refill) {
+			if (cnext >= cend) {
+				// A wave's first chunk is the one with its own number; later ones come from the shared cursor,
+				// which therefore starts behind those.  A launch over a short queue then costs no atomics at
+				// all (one address takes only ~90 of them per microsecond, and the grid has thousands of waves).
+				unsigned base = 0;
+				if (firstChunk) {
+					base = (blockIdx.x * (TRACE_THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6)) * (unsigned)chunk;
+					firstChunk = false;
+				}
+				else {
+					if (lane == 0) base = atomicAdd(work, (unsigned)chunk);
+					base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + gridDim.x * (TRACE_THREADS / 64) * (unsigned)chunk;
+				}
+				if (base >= (unsigned)n) {
+					more = false;
+					cnext = cend = 0;
+				}
+				else {
+					cnext = (int)base;
+					cend = min((int)base + chunk, n);
+				}
+			}
+			const int take = min(nidle, cend - cnext);
+			if (take > 0) {
+				const int slot = __popcll(idle & below);
+				if (!busy && slot < take) {
+					j = cnext + slot;
+					if (list) j = list[j];
+					float4 O = rayO[j];
+					float4 D = rayD[j];
+					if (D.w != 0.0f) {
+						hits[j] = make_float4(__int_as_float(-2), FLT_MAX, 0.0f, 0.0f);
+					}
+					else {
+						r.ox = O.x; r.oy = O.y; r.oz = O.z;
+						dx = D.x; dy = D.y; dz = D.z;
+						r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
+						r.nx = (__float_as_uint(r.ix) >> 31) != 0;
+						r.ny = (__float_as_uint(r.iy) >> 31) != 0;
+						r.nz = (__float_as_uint(r.iz) >> 31) != 0;
+						// Position-space slack for culling: 2^-14 of the largest coordinate magnitude in play.
+						float scale = fmaxf(fmaxf(sc.sceneAbsMax, fabsf(r.ox)), fmaxf(fabsf(r.oy), fabsf(r.oz)));
+						float eps = scale * 6.103515625e-05f;
+						r.mx = eps * fabsf(r.ix); r.my = eps * fabsf(r.iy); r.mz = eps * fabsf(r.iz);
+						best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
+						found = false;
+						sp = 0;
+						cur = 0;
+						pend0 = pend1 = -1;
+						busy = true;
+						// Rays no triangle can accept are answered without traversal.  A zero direction (the
+						// reference produces one when a diffuse offset cancels the normal, src/Triangle.cpp:115)
+						// makes n.d = +-0, so t is +-inf or NaN and the hit point NaN; a non-finite direction or
+						// a NaN origin makes t NaN or zero.  Triangle::hit rejects all of these
+						// (src/Triangle.cpp:28-29,84), yet BVH::hit would hand it a large part of the tree.
+						if (!EXHAUSTIVE) {
+							const bool zero = (dx == 0.0f) & (dy == 0.0f) & (dz == 0.0f);
+							const bool finite = (fabsf(dx) <= FLT_MAX) & (fabsf(dy) <= FLT_MAX) & (fabsf(dz) <= FLT_MAX) &
+												(r.ox == r.ox) & (r.oy == r.oy) & (r.oz == r.oz);
+							if (zero | !finite) cur = -1;
+						}
+					}
+				}
+				cnext += take;
+			}
+		}
+		const bool canWalk = busy && cur >= 0 && pend0 < 0;
+		const unsigned long long mWalk = __ballot(canWalk);
+		const unsigned long long mPark = __ballot(busy && pend0 >= 0);
+		if (mWalk == 0ull && mPark == 0ull) {
+			if (__ballot(busy) == 0ull) {
+				if (!more) break;
+				continue;
+			}
+		}
+		else if (__popcll(mPark) >= triBatch || mWalk == 0ull) {
+			// triangle phase; a second round serves the lanes that parked two leaves
+			for (int rep = 0; rep < 2; ++rep) {
+				if (busy && pend0 >= 0) {
+					if (STATS) triTests++;
+					found |= tri_test(sc.triHit, pend0, r.ox, r.oy, r.oz, dx, dy, dz, best);
+					pend0 = pend1;
+					pend1 = -1;
+					if (ANYHIT && found) {
+						pend0 = -1;
+						cur = -1;
+					}
+				}
+				if (__ballot(busy && pend0 >= 0) == 0ull) break;
+			}
+		}
+		else if (canWalk) {
+			const float4* P = sc.pairs + (size_t)cur * 4;
+			float4 lmin = P[0], lmax = P[1], rmin = P[2], rmax = P[3];
+			int codeL = __float_as_int(lmin.w);
+			int codeR = __float_as_int(rmin.w);
+			float teL, txL, teR, txR;
+			bool hitL = box_test(r, lmin, lmax, teL, txL) && codeL != 0;
+			bool hitR = box_test(r, rmin, rmax, teR, txR) && codeR != 0;
+			if (STATS) nodeTests += (codeL != 0) + (codeR != 0);
+			if (!EXHAUSTIVE) {
+				hitL = hitL && !(txL < 0.001f) && !(teL > best.t);
+				hitR = hitR && !(txR < 0.001f) && !(teR > best.t);
+			}
+			if (hitL && codeL < 0) pend0 = ~codeL;
+			if (hitR && codeR < 0) {
+				if (pend0 < 0) pend0 = ~codeR;
+				else pend1 = ~codeR;
+			}
+			const bool intL = hitL && codeL > 0;
+			const bool intR = hitR && codeR > 0;
+			int next = -1;
+			if (intL && intR) {
+				bool lfirst = teL <= teR;
+				next = lfirst ? codeL : codeR;
+				if (sp < STACK) {  // the host rejects trees deeper than the stack
+					stk[sp][tid] = lfirst ? codeR : codeL;
+					sp++;
+				}
+			}
+			else if (intL) next = codeL;
+			else if (intR) next = codeR;
+			else if (sp > 0) {
+				sp--;
+				next = stk[sp][tid];
+			}
+			cur = next;
+		}
+		if (busy && cur < 0 && pend0 < 0) {
+			int id = found ? (ANYHIT ? 0 : best.rank) : -1;
+			hits[j] = make_float4(__int_as_float(id), best.t, best.alpha, best.beta);
+			busy = false;
+		}
+	}
+	if (STATS) {
+		// wave-level reduction, then one atomic per wave
+		for (int off = 32; off > 0; off >>= 1) {
+			nodeTests += __shfl_down(nodeTests, off, 64);
+			triTests += __shfl_down(triTests, off, 64);
+		}
+		if (lane == 0) {
+			atomicAdd(&stats[0], (unsigned long long)nodeTests);
+			atomicAdd(&stats[1], (unsigned long long)triTests);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wide traversal.
+//
+// For a ray whose three reciprocals 1/d are finite, every value the reference's slab test computes is
+// finite, and (bound - o) * (1/d) is monotone in `bound`.  A child box of the reference's tree lies
+// inside its parent's box exactly (both are min/max over vertex sets), so if the slab predicate
+// (src/BVH.cpp:14-41) passes for a leaf's own box it passes for every ancestor: for such rays the
+// candidate list of BVH::hit is exactly "the triangles whose own box passes".  The interior boxes only
+// prune, and any conservative bound may stand in for them.  This kernel therefore walks a 4-wide tree of
+// its own (rtx_wide.h) whose child boxes are quantised to 8 bits per coordinate inside the node's box,
+// rounded outwards, and tested inflated by the same position-space slack as the culling bounds.  Leaves
+// are tested with the exact predicate on their exact box (recomputed from the vertices) and the exact
+// Triangle::hit, and ties go to the reference's candidate order, so the result equals the reference's.
+//
+// A ray parallel to an axis (1/d = +-inf there) is walked here too.  On that axis the reference computes
+// +-inf, or NaN where the origin lies on a box plane.  Its folds over lanes 1 and 2 (y, z) skip a NaN, which
+// is the same as the unconstrained (-inf, +inf) a parent's wider slab gives, so the argument above still
+// holds.  A NaN in lane 0 (x) makes the reference accept the box whatever the other axes say, which a
+// parent need not do: a ray that meets that case at a leaf is set aside in a list for the binary-tree kernel
+// above, which evaluates every ancestor as the reference does; so are rays with a finite reciprocal beyond
+// 2^100 (whose products overflow) and rays that need more stack than this kernel has.  The quantised
+// tests are homogeneous in 1/d; they use +-2^100 in place of +-inf and so prune a parallel ray by
+// "origin inside the slab, give or take the slack".
+//
+// Node, 4 x 16 bytes:  px py pz sx                          (origin; sx, sy, sz: quantisation steps, powers of two)
+//                      lo.x[4] hi.x[4] lo.y[4] hi.y[4]      (one byte per child)
+//                      lo.z[4] hi.z[4] code0 code1
+//                      code2 code3 sy sz                       code > 0 node, < 0 ~rank, 0 absent
+constexpr float WIDE_MAX_INV = 1.2676506e30f;  // 2^100
+
+__device__ __forceinline__ float ubyte_f(unsigned v, int k) { return (float)((v >> (8 * k)) & 0xFFu); }
+
+template <int STACK, bool ANYHIT, bool STATS>
+__global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_trace_wide(DevScene sc, const float4* __restrict__ rayO,
+															   const float4* __restrict__ rayD, float4* __restrict__ hits,
+															   int n, unsigned long long* __restrict__ stats,
+															   unsigned* __restrict__ work, int* __restrict__ unsafeList,
+															   unsigned* __restrict__ unsafeCount, int refill, int chunk,
+															   int triBatch, const unsigned* __restrict__ nDev) {
+	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
+	__shared__ int stk[STACK][TRACE_THREADS];
+	const int tid = threadIdx.x;
+	const unsigned lane = (unsigned)tid & 63u;
+	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+	unsigned boxTests = 0, triTests = 0, nodeVisits = 0, leafFetches = 0;
+	unsigned walkIters = 0, leafIters = 0, walkLanes = 0, leafLanes = 0;  // wave-level, kept by lane 0
+	unsigned overflows = 0;
+	int cnext = 0, cend = 0;
+	bool more = true, firstChunk = true;
+	int j = -1, cur = -1, sp = 0;
+	RaySlab r;
+	r.ox = r.oy = r.oz = r.ix = r.iy = r.iz = r.mx = r.my = r.mz = 0.0f;
+	r.nx = r.ny = r.nz = false;
+	float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+	float wix = 0.0f, wiy = 0.0f, wiz = 0.0f;  // 1/d as the interior tests use it: +-inf replaced by +-2^100
+	HitState best;
+	best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
+	bool found = false, busy = false;
+	int pend0 = -1, pend1 = -1;
+
+	for (;;) {
+		const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
+		const int nidle = __popcll(idle);
+		if (more && nidle >= refill) {
+			if (cnext >= cend) {
+				// A wave's first chunk is the one with its own number; later ones come from the shared cursor,
+				// which therefore starts behind those.  A launch over a short queue then costs no atomics at
+				// all (one address takes only ~90 of them per microsecond, and the grid has thousands of waves).
+				unsigned base = 0;
+				if (firstChunk) {
+					base = (blockIdx.x * (TRACE_THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6)) * (unsigned)chunk;
+					firstChunk = false;
+				}
+				else {
+					if (lane == 0) base = atomicAdd(work, (unsigned)chunk);
+					base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + gridDim.x * (TRACE_THREADS / 64) * (unsigned)chunk;
+				}
+				if (base >= (unsigned)n) {
+					more = false;
+					cnext = cend = 0;
+				}
+				else {
+					cnext = (int)base;
+					cend = min((int)base + chunk, n);
+				}
+			}
+			const int take = min(nidle, cend - cnext);
+			if (take > 0) {
+				const int slot = __popcll(idle & below);
+				if (!busy && slot < take) {
+					j = cnext + slot;
+					float4 O = rayO[j];
+					float4 D = rayD[j];
+					if (D.w != 0.0f) {
+						hits[j] = make_float4(__int_as_float(-2), FLT_MAX, 0.0f, 0.0f);
+					}
+					else {
+						r.ox = O.x; r.oy = O.y; r.oz = O.z;
+						dx = D.x; dy = D.y; dz = D.z;
+						r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
+						const bool zero = (dx == 0.0f) & (dy == 0.0f) & (dz == 0.0f);
+						const bool finite = (fabsf(dx) <= FLT_MAX) & (fabsf(dy) <= FLT_MAX) & (fabsf(dz) <= FLT_MAX) &
+											(r.ox == r.ox) & (r.oy == r.oy) & (r.oz == r.oz);
+						const float aix = fabsf(r.ix), aiy = fabsf(r.iy), aiz = fabsf(r.iz);
+						const bool safe = ((aix <= WIDE_MAX_INV) | (aix > FLT_MAX)) & ((aiy <= WIDE_MAX_INV) | (aiy > FLT_MAX)) &
+										  ((aiz <= WIDE_MAX_INV) | (aiz > FLT_MAX));
+						if (zero | !finite) {
+							// no triangle can accept such a ray (see k_trace)
+							hits[j] = make_float4(__int_as_float(-1), FLT_MAX, 0.0f, 0.0f);
+						}
+						else if (!safe) {
+							unsafeList[atomicAdd(unsafeCount, 1u)] = j;
+						}
+						else {
+							r.nx = (__float_as_uint(r.ix) >> 31) != 0;
+							r.ny = (__float_as_uint(r.iy) >> 31) != 0;
+							r.nz = (__float_as_uint(r.iz) >> 31) != 0;
+							// The interior tests are homogeneous in 1/d, so on an axis the ray is parallel to a large
+							// finite reciprocal decides "origin inside the slab, give or take the slack" just as well.
+							wix = aix > FLT_MAX ? copysignf(WIDE_MAX_INV, r.ix) : r.ix;
+							wiy = aiy > FLT_MAX ? copysignf(WIDE_MAX_INV, r.iy) : r.iy;
+							wiz = aiz > FLT_MAX ? copysignf(WIDE_MAX_INV, r.iz) : r.iz;
+							float scale = fmaxf(fmaxf(sc.sceneAbsMax, fabsf(r.ox)), fmaxf(fabsf(r.oy), fabsf(r.oz)));
+							float eps = scale * 6.103515625e-05f;
+							r.mx = eps * fabsf(wix); r.my = eps * fabsf(wiy); r.mz = eps * fabsf(wiz);
+							best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
+							found = false;
+							sp = 0;
+							cur = 0;
+							pend0 = pend1 = -1;
+							busy = true;
+						}
+					}
+				}
+				cnext += take;
+			}
+		}
+		// A lane walks while it has something to walk and a free leaf slot: a leaf it comes across is kept
+		// for later (two slots) and the walk goes on to what lies behind it.  That is speculative (the leaf
+		// may turn out to cut those nodes off) but keeps lanes out of the waiting room; the result does not
+		// depend on the order of the tests.
+		const bool canWalk = busy && pend1 < 0 && (cur >= 0 || sp > 0);
+		const unsigned long long mWalk = __builtin_amdgcn_ballot_w64(canWalk);
+		const unsigned long long mLeaf = __builtin_amdgcn_ballot_w64(busy && pend0 >= 0);
+		if (mWalk == 0ull && mLeaf == 0ull) {
+			if (!more) break;
+			continue;
+		}
+		const bool leafPhase = __popcll(mLeaf) >= triBatch || mWalk == 0ull;
+		if (STATS) {
+			if (leafPhase) {
+				leafIters++;
+				leafLanes += __popcll(mLeaf);
+			}
+			else {
+				walkIters++;
+				walkLanes += __popcll(mWalk);
+			}
+		}
+		if (leafPhase) {
+			// exact box of the triangle, exact slab predicate, exact triangle test; one leaf per lane and pass
+			if (busy && pend0 >= 0) {
+				const float4* T = sc.triHit + (size_t)pend0 * 4;
+				float4 q0 = T[0], q1 = T[1], q2 = T[2];
+				if (STATS) leafFetches++;
+				const float v0x = q0.w, v0y = q1.x, v0z = q1.y, v1x = q1.z, v1y = q1.w, v1z = q2.x, v2x = q2.y, v2y = q2.z, v2z = q2.w;
+				// the reference's predicate on the leaf's own box (src/BVH.cpp:14-41); lane 0 is never NaN here and
+				// fmaxf/fminf skip a NaN in lanes 1 and 2 as the reference's folds do
+				const float lx = fminf(fminf(v0x, v1x), v2x), hx = fmaxf(fmaxf(v0x, v1x), v2x);
+				const float ly = fminf(fminf(v0y, v1y), v2y), hy = fmaxf(fmaxf(v0y, v1y), v2y);
+				const float lz = fminf(fminf(v0z, v1z), v2z), hz = fmaxf(fmaxf(v0z, v1z), v2z);
+				const float t0x = (lx - r.ox) * r.ix, t1x = (hx - r.ox) * r.ix;
+				const float t0y = (ly - r.oy) * r.iy, t1y = (hy - r.oy) * r.iy;
+				const float t0z = (lz - r.oz) * r.iz, t1z = (hz - r.oz) * r.iz;
+				const float tmin = fmaxf(fmaxf(r.nx ? t1x : t0x, r.ny ? t1y : t0y), r.nz ? t1z : t0z);
+				const float tmax = fminf(fminf(r.nx ? t0x : t1x, r.ny ? t0y : t1y), r.nz ? t0z : t1z);
+				const bool pass = !(tmax < tmin);
+				if (STATS) boxTests++;
+				if (t0x != t0x || t1x != t1x) {
+					// The origin lies on an x plane of this box and the ray runs along it: the reference accepts
+					// such a box whatever y and z say (NaN in lane 0), provided it gets there, which only its own
+					// tree can tell.  The ray starts over in the binary-tree kernel.
+					unsafeList[atomicAdd(unsafeCount, 1u)] = j;
+					busy = false;
+					cur = -1;
+					sp = 0;
+					pend1 = -1;
+				}
+				else if (pass) {
+					if (STATS) triTests++;
+					found |= tri_test_vals(q0.x, q0.y, q0.z, v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z, pend0, r.ox, r.oy,
+										   r.oz, dx, dy, dz, best);
+				}
+				pend0 = pend1;
+				pend1 = -1;
+				if (ANYHIT && found) {
+					pend0 = -1;
+					cur = -1;
+					sp = 0;
+				}
+			}
+		}
+		else if (canWalk) {
+			int item = 0;  // what this lane looks at next: > 0 node, < 0 ~rank of a leaf, 0 nothing yet
+			if (cur >= 0) {
+				const float4* W = sc.wide + (size_t)cur * 4;
+				float4 w0 = W[0], w1 = W[1], w2 = W[2], w3 = W[3];
+				if (STATS) nodeVisits++;
+				const float Sx = w0.w * wix, Sy = w3.z * wiy, Sz = w3.w * wiz;
+				const float Ax = (w0.x - r.ox) * wix, Ay = (w0.y - r.oy) * wiy, Az = (w0.z - r.oz) * wiz;
+				const float Anx = Ax - r.mx, Any = Ay - r.my, Anz = Az - r.mz;
+				const float Afx = Ax + r.mx, Afy = Ay + r.my, Afz = Az + r.mz;
+				const unsigned lox = __float_as_uint(w1.x), hix = __float_as_uint(w1.y), loy = __float_as_uint(w1.z),
+							   hiy = __float_as_uint(w1.w), loz = __float_as_uint(w2.x), hiz = __float_as_uint(w2.y);
+				const unsigned nxd = r.nx ? hix : lox, fxd = r.nx ? lox : hix;
+				const unsigned nyd = r.ny ? hiy : loy, fyd = r.ny ? loy : hiy;
+				const unsigned nzd = r.nz ? hiz : loz, fzd = r.nz ? loz : hiz;
+				int cd[4] = {__float_as_int(w2.z), __float_as_int(w2.w), __float_as_int(w3.x), __float_as_int(w3.y)};
+				// key: ordered bits of what the children are sorted by, all ones for a child that is not entered
+				unsigned key[4];
+				int nh = 0;
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					float e = fmaxf(fmaxf(__fmaf_rn(ubyte_f(nxd, c), Sx, Anx), __fmaf_rn(ubyte_f(nyd, c), Sy, Any)),
+									__fmaf_rn(ubyte_f(nzd, c), Sz, Anz));
+					float x = fminf(fminf(__fmaf_rn(ubyte_f(fxd, c), Sx, Afx), __fmaf_rn(ubyte_f(fyd, c), Sy, Afy)),
+									__fmaf_rn(ubyte_f(fzd, c), Sz, Afz));
+					e = fmaxf(e, 0.001f);
+					const bool h = (cd[c] != 0) & !(x < e) & !(e > best.t);
+					// closest hit: nearest child first.  Any hit: the child the ray stays in longest first, where an
+					// occluder is likeliest (any order gives the same answer; the key stays below the "not
+					// entered" marker because the length is clamped to >= +0).
+					key[c] = !h ? 0xFFFFFFFFu : ANYHIT ? 0x7FFFFFFFu - __float_as_uint(fmaxf(x - e, 0.0f)) : __float_as_uint(e);
+					nh += h ? 1 : 0;
+					if (STATS) boxTests += cd[c] != 0;
+				}
+				// sorting network on (key, code), nearest first
+#define RTX_CSWAP(i, j)                                     \
+	{                                                       \
+		const bool sw = key[i] > key[j];                    \
+		const unsigned klo = min(key[i], key[j]);           \
+		const unsigned khi = max(key[i], key[j]);           \
+		const int ci = sw ? cd[j] : cd[i];                  \
+		const int cj = sw ? cd[i] : cd[j];                  \
+		key[i] = klo; key[j] = khi; cd[i] = ci; cd[j] = cj; \
+	}
+				RTX_CSWAP(0, 1)
+				RTX_CSWAP(2, 3)
+				RTX_CSWAP(0, 2)
+				RTX_CSWAP(1, 3)
+				RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+				// the nearest is looked at next, the others wait with the farthest at the bottom
+				if (sp + nh - 1 > STACK) {
+					// no room: the ray starts over in the binary-tree kernel, whose stack covers its whole tree
+					unsafeList[atomicAdd(unsafeCount, 1u)] = j;
+					if (STATS) overflows++;
+					busy = false;
+					sp = 0;
+					nh = 0;
+					pend0 = -1;
+				}
+				if (nh > 3) stk[sp][tid] = cd[3];
+				if (nh > 2) stk[sp + nh - 3][tid] = cd[2];
+				if (nh > 1) stk[sp + nh - 2][tid] = cd[1];
+				sp += max(nh - 1, 0);
+				item = nh > 0 ? cd[0] : 0;
+				cur = -1;
+			}
+			if (item == 0 && sp > 0) {
+				sp--;
+				item = stk[sp][tid];
+			}
+			if (item < 0) {
+				// a leaf: keep it and look at what comes after it
+				if (pend0 < 0) pend0 = ~item;
+				else pend1 = ~item;
+				item = 0;
+				if (pend1 < 0 && sp > 0) {
+					sp--;
+					item = stk[sp][tid];
+					if (item < 0) {
+						pend1 = ~item;
+						item = 0;
+					}
+				}
+			}
+			if (item > 0) cur = item;
+		}
+		if (busy && cur < 0 && pend0 < 0 && sp == 0) {
+			int id = found ? (ANYHIT ? 0 : best.rank) : -1;
+			hits[j] = make_float4(__int_as_float(id), best.t, best.alpha, best.beta);
+			busy = false;
+		}
+	}
+	if (STATS) {
+		for (int off = 32; off > 0; off >>= 1) {
+			boxTests += __shfl_down(boxTests, off, 64);
+			triTests += __shfl_down(triTests, off, 64);
+			nodeVisits += __shfl_down(nodeVisits, off, 64);
+			leafFetches += __shfl_down(leafFetches, off, 64);
+		}
+		if (lane == 0) {
+			atomicAdd(&stats[0], (unsigned long long)boxTests);
+			atomicAdd(&stats[1], (unsigned long long)triTests);
+			atomicAdd(&stats[4], (unsigned long long)nodeVisits);
+			atomicAdd(&stats[5], (unsigned long long)leafFetches);
+			atomicAdd(&stats[2], (unsigned long long)walkIters);
+			atomicAdd(&stats[3], (unsigned long long)walkLanes);
+			atomicAdd(&stats[6], (unsigned long long)leafIters);
+			atomicAdd(&stats[7], (unsigned long long)leafLanes);
+		}
+		for (int off = 32; off > 0; off >>= 1) overflows += __shfl_down(overflows, off, 64);
+		if (lane == 0) {
+			atomicAdd(&stats[8], (unsigned long long)overflows);
+		}
+	}
+}
+
+}  // namespace

@@ -24,11 +24,17 @@
 // reference has explicit FMA intrinsics (src/Triangle.cpp:66,79), and transcendental values
 // come from host-computed tables.
 //
-// Traversal visits exactly the candidates the reference visits (same slab predicate per
-// node, src/BVH.cpp:14-41) minus nodes that provably cannot hold the winner: boxes wholly
-// behind t = 0.001 or wholly beyond the best hit so far, judged on boxes inflated by a
-// position-space safety margin.  Equal-t ties are resolved by the reference's depth-first
-// (right child first) candidate order, which is precomputed per triangle.
+// Traversal (rtx_dev_trace.h): for a ray with finite reciprocals the reference's candidate list is exactly
+// the triangles whose own bounding box passes its slab predicate (src/BVH.cpp:14-41), in its depth-first
+// (right child first) leaf order.  The kernels therefore walk a 4-wide quantised tree of their own
+// (rtx_wide.h), test every leaf with the exact predicate and the exact Triangle::hit, skip boxes that lie
+// wholly behind t = 0.001 or beyond the best hit (judged on boxes inflated by a position-space margin) and
+// resolve equal-t ties by the precomputed leaf order.  The few rays that argument does not cover are traced
+// through the reference's own tree.
+//
+// Files: rtx_dev_common.h (scene description, RNG, texture/sky), rtx_dev_trace.h (traversal kernels),
+// rtx_dev_shade.h (ray generation, shade, gather, accumulate, tone map, exports), this file (host side and
+// the C ABI), rtx_wide.h (construction of the traversal tree).
 
 #include <hip/hip_runtime.h>
 
@@ -63,1269 +69,13 @@ int fail(int code, const std::string& msg) {
 			return fail(RTX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));            \
 	} while (0)
 
-// ------------------------------------------------------------------------------------------------
-// Device-side scene description, passed to kernels by value.
+}  // namespace
 
-constexpr int TILE = 64;            // image tile edge in pixels (sharding granule)
-constexpr int BLK = 4;              // a wave covers a BLK x BLK pixel block x 4 sub-samples
-constexpr int BLOCKS_PER_TILE = (TILE / BLK) * (TILE / BLK);
-constexpr int SAMPLES_PER_BLOCK = BLK * BLK * 4;  // 64 = one wave
-constexpr int TRACE_THREADS = 256;
+#include "rtx_dev_common.h"
+#include "rtx_dev_trace.h"
+#include "rtx_dev_shade.h"
 
-enum NodeKind : int { KIND_LEAF = 0, KIND_METAL = 1, KIND_TRANSP = 2, KIND_DIEL = 3 };
-constexpr int FLAG_TEX = 0x100;
-constexpr int FLAG_TIR = 0x200;
-
-constexpr int TRI_EMIT = 1, TRI_METAL = 2, TRI_TRANSP = 4;
-
-struct DevScene {
-	const float4* pairs;     // 4 x float4 per child pair: Lmin|codeL, Lmax|-, Rmin|codeR, Rmax|-
-	const float4* wide;      // 4 x float4 per node of the 4-wide quantised collapse of the tree
-	const float4* triHit;    // 4 x float4 per triangle in candidate-rank order: n, v0, v1, v2, index
-	const float4* triShade;  // 4 x float4 per triangle in candidate-rank order: n0 r | n1 g | n2 b | rough ior tex flags
-	const float4* triUv;     // 2 x float4 per triangle: uv0 uv1 | uv2 - -   (read for textured hits only)
-	const uint8_t* texels;
-	const int4* texDesc;     // byte offset, width, height
-	const float* cosT;
-	const float* sinT;
-	const float* gammaT;
-	float4 camO, camLUC, camRS, camDS;
-	float4 bg;
-	int width, height, maxDepth, nDiff, nSpec;
-	int hasSky;
-	float skyBrightness;
-	int skyTex[6];
-	uint32_t seedKey;
-	float sceneAbsMax;
-	int tilesX;
-};
-
-// ------------------------------------------------------------------------------------------------
-// Small device helpers.  dot4 is Eigen's reduction order with the (zero) w lane kept as "+ 0.0f".
-
-__device__ __forceinline__ float dot3w(float ax, float ay, float az, float bx, float by, float bz) {
-	return (ax * bx + az * bz) + (ay * by + 0.0f);
-}
-
-__device__ __forceinline__ uint32_t rt_mix(uint32_t h, uint32_t v) {
-	h = (h + 0x7F4A7C15u) ^ (v * 0x9E3779B1u);
-	h ^= h >> 16;
-	h *= 0x85EBCA6Bu;
-	h ^= h >> 13;
-	h *= 0xC2B2AE35u;
-	h ^= h >> 16;
-	return h;
-}
-__device__ __forceinline__ uint32_t rt_child_key(uint32_t key, uint32_t ordinal) { return rt_mix(key, 1u + ordinal); }
-__device__ __forceinline__ uint32_t rt_draw(uint32_t key, uint32_t lobe, uint32_t k, uint32_t dim) {
-	return rt_mix(key, 0x80000000u | (lobe << 20) | (k << 1) | dim);
-}
-
-__device__ __forceinline__ float clamp01(float u) {
-	u = (u >= 0.0f) ? u : 0.0f;
-	u = (u <= 1.0f) ? u : 1.0f;
-	return u;
-}
-
-// Texture::sampleTexture (src/Texture.cpp:41-53) with clamped coordinates and the
-// powf(c/255, 2.2) decode taken from the host-computed table.
-__device__ __forceinline__ float3 tex_fetch(const DevScene& sc, int id, float u, float v) {
-	int4 d = sc.texDesc[id];
-	u = clamp01(u);
-	v = clamp01(v);
-	float uMax = (float)(d.y - 1);
-	float vMax = (float)(d.z - 1);
-	int sx = (int)roundf(u * uMax);
-	int sy = (int)roundf(v * vMax);
-	const uint8_t* c = sc.texels + (size_t)(uint32_t)d.x + ((size_t)sy * (size_t)d.y + (size_t)sx) * 3;
-	return make_float3(sc.gammaT[c[0]], sc.gammaT[c[1]], sc.gammaT[c[2]]);
-}
-
-// Skybox::sampleBackground (src/Skybox.cpp:32-84).
-__device__ float3 sky_fetch(const DevScene& sc, float dx, float dy, float dz) {
-	for (int i = 0; i < 6; ++i) {
-		float divisor, u, v;
-		float px, py, pz;
-		switch (i) {
-		case 0:
-			divisor = dz;
-			px = dx / divisor; py = dy / divisor;
-			u = (1.0f - px) * 0.5f;
-			v = (1.0f + py) * 0.5f;
-			break;
-		case 1:
-			divisor = -dz;
-			px = dx / divisor; py = dy / divisor;
-			u = (1.0f + px) * 0.5f;
-			v = (1.0f + py) * 0.5f;
-			break;
-		case 2:
-			divisor = -dx;
-			pz = dz / divisor; py = dy / divisor;
-			u = (1.0f - pz) * 0.5f;
-			v = (1.0f + py) * 0.5f;
-			break;
-		case 3:
-			divisor = dx;
-			pz = dz / divisor; py = dy / divisor;
-			u = (pz + 1.0f) * 0.5f;
-			v = (py + 1.0f) * 0.5f;
-			break;
-		case 4:
-			divisor = dy;
-			px = dx / divisor; pz = dz / divisor;
-			u = (px + 1.0f) * 0.5f;
-			v = (pz + 1.0f) * 0.5f;
-			break;
-		default:
-			divisor = -dy;
-			px = dx / divisor; pz = dz / divisor;
-			u = (px + 1.0f) * 0.5f;
-			v = (pz - 1.0f) * 0.5f;
-			break;
-		}
-		if (divisor < 0.0f || u < 0.0f || v < 0.0f || u > 1.0f || v > 1.0f) continue;
-		float3 c = tex_fetch(sc, sc.skyTex[i], u, v);
-		return make_float3(c.x * sc.skyBrightness, c.y * sc.skyBrightness, c.z * sc.skyBrightness);
-	}
-	return make_float3(0.0f, 0.0f, 0.0f);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Level-0 sample order.  Sample j of a batch that starts at pixel block g0:
-//   block g = g0 + j/64 -> (tile slot, block in tile); lane = j%64 -> (pixel in block, sub-sample).
-// A wave therefore holds the 4 sub-samples of a 4x4 pixel block, which keeps primary rays of
-// one wave spatially adjacent.  Tiles are taken from the arithmetic list first + k*stride.
-
-struct Batch {
-	int g0;          // first pixel block (global over the scene's tile list)
-	int nSamples;    // (number of blocks) * 64
-	int tileFirst, tileStride;
-};
-
-__device__ __forceinline__ bool sample_to_pixel(const DevScene& sc, const Batch& b, int j, int& x, int& y, int& sub) {
-	int g = b.g0 + (j >> 6);
-	int lane = j & 63;
-	int slot = g / BLOCKS_PER_TILE;
-	int blk = g - slot * BLOCKS_PER_TILE;
-	int tile = b.tileFirst + slot * b.tileStride;
-	int ty = tile / sc.tilesX;
-	int tx = tile - ty * sc.tilesX;
-	int by = blk / (TILE / BLK);
-	int bx = blk - by * (TILE / BLK);
-	int pix = lane >> 2;
-	sub = lane & 3;
-	x = tx * TILE + bx * BLK + (pix & 3);
-	y = ty * TILE + by * BLK + (pix >> 2);
-	return x < sc.width && y < sc.height;
-}
-
-// Camera::getRay (src/Camera.cpp:37-49) plus the per-sample RNG key.
-__global__ __launch_bounds__(256) void k_raygen(DevScene sc, Batch b, uint32_t frame, float4* __restrict__ rayO,
-												float4* __restrict__ rayD) {
-	int j = blockIdx.x * 256 + threadIdx.x;
-	if (j >= b.nSamples) return;
-	int x, y, sub;
-	bool valid = sample_to_pixel(sc, b, j, x, y, sub);
-	if (!valid) {
-		rayO[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-		rayD[j] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);  // w = 1 marks a dead slot
-		return;
-	}
-	const float xo = (sub & 1) ? 0.25f : -0.25f;
-	const float yo = (sub & 2) ? 0.25f : -0.25f;
-	float xTemp = (float)x + xo;
-	float yTemp = (float)y + yo;
-	float dx = (sc.camLUC.x + xTemp * sc.camRS.x) + yTemp * sc.camDS.x;
-	float dy = (sc.camLUC.y + xTemp * sc.camRS.y) + yTemp * sc.camDS.y;
-	float dz = (sc.camLUC.z + xTemp * sc.camRS.z) + yTemp * sc.camDS.z;
-	uint32_t sample = ((uint32_t)y * (uint32_t)sc.width + (uint32_t)x) * 4u + (uint32_t)sub;
-	uint32_t key = rt_mix(rt_mix(sc.seedKey, frame), sample);
-	rayO[j] = make_float4(sc.camO.x, sc.camO.y, sc.camO.z, __uint_as_float(key));
-	rayD[j] = make_float4(dx, dy, dz, 0.0f);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Traversal.
-
-struct HitState {
-	float t, alpha, beta;
-	int rank;
-};
-
-// Triangle::hit (src/Triangle.cpp:23-93) for plane normal n and vertices v0, v1, v2, folded with the
-// closest-hit rule of src/RayTracer.cpp:145 extended by the candidate-order tie break.
-// Returns true when the triangle was accepted (any-hit callers stop there).
-__device__ __forceinline__ bool tri_test_vals(float nx, float ny, float nz, float v0x, float v0y, float v0z, float v1x,
-											  float v1y, float v1z, float v2x, float v2y, float v2z, int rank, float ox,
-											  float oy, float oz, float dx, float dy, float dz, HitState& best) {
-	float temp = dot3w(nx, ny, nz, v0x - ox, v0y - oy, v0z - oz);
-	float t = temp / dot3w(nx, ny, nz, dx, dy, dz);
-	if (!(t > 0.001f)) return false;
-	if (t > best.t || (t == best.t && rank > best.rank)) return false;
-	float bx = (ox + t * dx) - v2x;
-	float by = (oy + t * dy) - v2y;
-	float bz = (oz + t * dz) - v2z;
-	// rows (a1_i, a2_i, b_i), i = x,y,z with a1 = v0 - v2, a2 = v1 - v2 (src/Triangle.cpp:31-32)
-	float r00 = v0x - v2x, r01 = v1x - v2x, r02 = bx;
-	float r10 = v0y - v2y, r11 = v1y - v2y, r12 = by;
-	float r20 = v0z - v2z, r21 = v1z - v2z, r22 = bz;
-	// first pivot: largest |column 0|, strict >, rows tried in order 0,1,2
-	bool s1 = fabsf(r10) > fabsf(r00);
-	float mx = s1 ? fabsf(r10) : fabsf(r00);
-	bool s2 = fabsf(r20) > mx;
-	float p0 = s2 ? r20 : (s1 ? r10 : r00);
-	float p1 = s2 ? r21 : (s1 ? r11 : r01);
-	float p2 = s2 ? r22 : (s1 ? r12 : r02);
-	bool m1 = s1 && !s2;
-	float a0 = m1 ? r00 : r10, a1 = m1 ? r01 : r11, a2 = m1 ? r02 : r12;  // new row 1
-	float c0 = s2 ? r00 : r20, c1 = s2 ? r01 : r21, c2 = s2 ? r02 : r22;  // new row 2
-	p1 = p1 / p0;
-	p2 = p2 / p0;
-	a1 = __fmaf_rn(-p1, a0, a1);
-	a2 = __fmaf_rn(-p2, a0, a2);
-	c1 = __fmaf_rn(-p1, c0, c1);
-	c2 = __fmaf_rn(-p2, c0, c2);
-	// second pivot
-	bool s3 = fabsf(c1) > fabsf(a1);
-	float e1 = s3 ? c1 : a1;
-	float e2 = s3 ? c2 : a2;
-	e2 = e2 / e1;
-	float alpha = __fmaf_rn(-e2, p1, p2);
-	float beta = e2;
-	bool accept = (0.0f <= alpha) & (alpha <= 1.0f) & (0.0f <= beta) & (beta <= 1.0f) & (alpha + beta <= 1.0f);
-	if (!accept) return false;
-	best.t = t;
-	best.alpha = alpha;
-	best.beta = beta;
-	best.rank = rank;
-	return true;
-}
-
-// The triangle stored at `rank`: q0 = n.xyz v0.x | q1 = v0.yz v1.xy | q2 = v1.z v2.xyz | q3 = id - - -
-__device__ __forceinline__ bool tri_test(const float4* __restrict__ triHit, int rank, float ox, float oy, float oz,
-										 float dx, float dy, float dz, HitState& best) {
-	const float4* T = triHit + (size_t)rank * 4;
-	float4 q0 = T[0], q1 = T[1], q2 = T[2];
-	return tri_test_vals(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, rank, ox, oy, oz, dx, dy,
-						 dz, best);
-}
-
-// Per-ray constants of the slab test.
-struct RaySlab {
-	float ox, oy, oz, ix, iy, iz, mx, my, mz;
-	bool nx, ny, nz;
-};
-
-// AABB::hit (src/BVH.cpp:14-41) for one box, plus the conservative entry/exit bounds used
-// for culling.  The folds over lanes 1 and 2 ignore NaN exactly like the reference's
-// "t0 > tmin ? t0 : tmin"; a NaN in lane 0 makes the reference's final comparison false,
-// i.e. a hit, which the unordered test reproduces.
-__device__ __forceinline__ bool box_test(const RaySlab& r, float4 bmin, float4 bmax, float& te, float& tx) {
-	float t0x = (bmin.x - r.ox) * r.ix, t1x = (bmax.x - r.ox) * r.ix;
-	float t0y = (bmin.y - r.oy) * r.iy, t1y = (bmax.y - r.oy) * r.iy;
-	float t0z = (bmin.z - r.oz) * r.iz, t1z = (bmax.z - r.oz) * r.iz;
-	float nX = r.nx ? t1x : t0x, fX = r.nx ? t0x : t1x;
-	float nY = r.ny ? t1y : t0y, fY = r.ny ? t0y : t1y;
-	float nZ = r.nz ? t1z : t0z, fZ = r.nz ? t0z : t1z;
-	float tmin = fmaxf(fmaxf(nX, nY), nZ);
-	float tmax = fminf(fminf(fX, fY), fZ);
-	bool hit = !(tmax < tmin) || (nX != nX) || (fX != fX);
-	te = fmaxf(fmaxf(nX - r.mx, nY - r.my), nZ - r.mz);
-	tx = fminf(fminf(fX + r.mx, fY + r.my), fZ + r.mz);
-	return hit;
-}
-
-// hits[j] = (rank or -1 / -2 for a dead slot, t, alpha, beta), all as raw bits of a float4.
-// ANYHIT: only "some candidate is accepted" is needed (rays at the last recursion depth,
-// src/RayTracer.cpp:154-171); x = 0 then stands for "hit".
-// EXHAUSTIVE: no culling, i.e. the candidate set of BVH::hit itself.
-//
-// Persistent waves: rays of one queue differ in traversal length by orders of magnitude, so a wave
-// that takes 64 rays and waits for the slowest runs mostly empty.  Here a wave keeps running and, once
-// REFILL or more of its lanes are idle, hands them the next rays of its private chunk of the queue
-// (CHUNK consecutive rays claimed with one atomic on *work, which the host zeroes before the launch).
-// Every wave leaves the loop when the queue is exhausted and its lanes have drained.
-constexpr int TRACE_CHUNK = 256;
-constexpr int TRACE_REFILL = 16;
-
-template <int STACK, bool ANYHIT, bool EXHAUSTIVE, bool STATS>
-__global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const float4* __restrict__ rayO,
-														  const float4* __restrict__ rayD, float4* __restrict__ hits,
-														  int n, unsigned long long* __restrict__ stats,
-														  unsigned* __restrict__ work, int refill, int chunk, int triBatch,
-														  const int* __restrict__ list, const unsigned* __restrict__ listCount,
-														  const unsigned* __restrict__ nDev) {
-	// the queue length may live on the device (written by the previous level's shade kernel); n is then the
-	// capacity of the arrays
-	if (nDev) n = (int)min(*nDev, (unsigned)n);
-	// with a list: the rays to trace are list[0 .. *listCount), the ones the wide traversal set aside
-	if (list) n = (int)*listCount;
-	__shared__ int stk[STACK][TRACE_THREADS];
-	const int tid = threadIdx.x;
-	const unsigned lane = (unsigned)tid & 63u;
-	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-
-	unsigned nodeTests = 0, triTests = 0;
-	// wave-uniform: the chunk this wave is handing out
-	int cnext = 0, cend = 0;
-	bool more = true, firstChunk = true;
-	// per lane: the ray in flight (cur < 0: none)
-	int j = -1, cur = -1, sp = 0;
-	RaySlab r;
-	r.ox = r.oy = r.oz = r.ix = r.iy = r.iz = r.mx = r.my = r.mz = 0.0f;
-	r.nx = r.ny = r.nz = false;
-	float dx = 0.0f, dy = 0.0f, dz = 0.0f;
-	HitState best;
-	best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
-	bool found = false;
-
-	// Leaf children are not intersected where they are found: a lane parks them (at most two, the two
-	// children of one pair) and waits.  Once triBatch lanes are parked, or nobody can traverse any more,
-	// the wave runs the triangle code once for all of them.  The address path issues one vector-memory
-	// instruction per ~22 clocks per CU however few lanes it serves, so four loads for one or two lanes
-	// per step would cost as much as the box loads of the whole wave.
-	bool busy = false;
-	int pend0 = -1, pend1 = -1;
-	for (;;) {
-		const unsigned long long idle = __ballot(!busy);
-		const int nidle = __popcll(idle);
-		if (more && nidle >= refill) {
-			if (cnext >= cend) {
-				// A wave's first chunk is the one with its own number; later ones come from the shared cursor,
-				// which therefore starts behind those.  A launch over a short queue then costs no atomics at
-				// all (one address takes only ~90 of them per microsecond, and the grid has thousands of waves).
-				unsigned base = 0;
-				if (firstChunk) {
-					base = (blockIdx.x * (TRACE_THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6)) * (unsigned)chunk;
-					firstChunk = false;
-				}
-				else {
-					if (lane == 0) base = atomicAdd(work, (unsigned)chunk);
-					base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + gridDim.x * (TRACE_THREADS / 64) * (unsigned)chunk;
-				}
-				if (base >= (unsigned)n) {
-					more = false;
-					cnext = cend = 0;
-				}
-				else {
-					cnext = (int)base;
-					cend = min((int)base + chunk, n);
-				}
-			}
-			const int take = min(nidle, cend - cnext);
-			if (take > 0) {
-				const int slot = __popcll(idle & below);
-				if (!busy && slot < take) {
-					j = cnext + slot;
-					if (list) j = list[j];
-					float4 O = rayO[j];
-					float4 D = rayD[j];
-					if (D.w != 0.0f) {
-						hits[j] = make_float4(__int_as_float(-2), FLT_MAX, 0.0f, 0.0f);
-					}
-					else {
-						r.ox = O.x; r.oy = O.y; r.oz = O.z;
-						dx = D.x; dy = D.y; dz = D.z;
-						r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
-						r.nx = (__float_as_uint(r.ix) >> 31) != 0;
-						r.ny = (__float_as_uint(r.iy) >> 31) != 0;
-						r.nz = (__float_as_uint(r.iz) >> 31) != 0;
-						// Position-space slack for culling: 2^-14 of the largest coordinate magnitude in play.
-						float scale = fmaxf(fmaxf(sc.sceneAbsMax, fabsf(r.ox)), fmaxf(fabsf(r.oy), fabsf(r.oz)));
-						float eps = scale * 6.103515625e-05f;
-						r.mx = eps * fabsf(r.ix); r.my = eps * fabsf(r.iy); r.mz = eps * fabsf(r.iz);
-						best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
-						found = false;
-						sp = 0;
-						cur = 0;
-						pend0 = pend1 = -1;
-						busy = true;
-						// Rays no triangle can accept are answered without traversal.  A zero direction (the
-						// reference produces one when a diffuse offset cancels the normal, src/Triangle.cpp:115)
-						// makes n.d = +-0, so t is +-inf or NaN and the hit point NaN; a non-finite direction or
-						// a NaN origin makes t NaN or zero.  Triangle::hit rejects all of these
-						// (src/Triangle.cpp:28-29,84), yet BVH::hit would hand it a large part of the tree.
-						if (!EXHAUSTIVE) {
-							const bool zero = (dx == 0.0f) & (dy == 0.0f) & (dz == 0.0f);
-							const bool finite = (fabsf(dx) <= FLT_MAX) & (fabsf(dy) <= FLT_MAX) & (fabsf(dz) <= FLT_MAX) &
-												(r.ox == r.ox) & (r.oy == r.oy) & (r.oz == r.oz);
-							if (zero | !finite) cur = -1;
-						}
-					}
-				}
-				cnext += take;
-			}
-		}
-		const bool canWalk = busy && cur >= 0 && pend0 < 0;
-		const unsigned long long mWalk = __ballot(canWalk);
-		const unsigned long long mPark = __ballot(busy && pend0 >= 0);
-		if (mWalk == 0ull && mPark == 0ull) {
-			if (__ballot(busy) == 0ull) {
-				if (!more) break;
-				continue;
-			}
-		}
-		else if (__popcll(mPark) >= triBatch || mWalk == 0ull) {
-			// triangle phase; a second round serves the lanes that parked two leaves
-			for (int rep = 0; rep < 2; ++rep) {
-				if (busy && pend0 >= 0) {
-					if (STATS) triTests++;
-					found |= tri_test(sc.triHit, pend0, r.ox, r.oy, r.oz, dx, dy, dz, best);
-					pend0 = pend1;
-					pend1 = -1;
-					if (ANYHIT && found) {
-						pend0 = -1;
-						cur = -1;
-					}
-				}
-				if (__ballot(busy && pend0 >= 0) == 0ull) break;
-			}
-		}
-		else if (canWalk) {
-			const float4* P = sc.pairs + (size_t)cur * 4;
-			float4 lmin = P[0], lmax = P[1], rmin = P[2], rmax = P[3];
-			int codeL = __float_as_int(lmin.w);
-			int codeR = __float_as_int(rmin.w);
-			float teL, txL, teR, txR;
-			bool hitL = box_test(r, lmin, lmax, teL, txL) && codeL != 0;
-			bool hitR = box_test(r, rmin, rmax, teR, txR) && codeR != 0;
-			if (STATS) nodeTests += (codeL != 0) + (codeR != 0);
-			if (!EXHAUSTIVE) {
-				hitL = hitL && !(txL < 0.001f) && !(teL > best.t);
-				hitR = hitR && !(txR < 0.001f) && !(teR > best.t);
-			}
-			if (hitL && codeL < 0) pend0 = ~codeL;
-			if (hitR && codeR < 0) {
-				if (pend0 < 0) pend0 = ~codeR;
-				else pend1 = ~codeR;
-			}
-			const bool intL = hitL && codeL > 0;
-			const bool intR = hitR && codeR > 0;
-			int next = -1;
-			if (intL && intR) {
-				bool lfirst = teL <= teR;
-				next = lfirst ? codeL : codeR;
-				if (sp < STACK) {  // the host rejects trees deeper than the stack
-					stk[sp][tid] = lfirst ? codeR : codeL;
-					sp++;
-				}
-			}
-			else if (intL) next = codeL;
-			else if (intR) next = codeR;
-			else if (sp > 0) {
-				sp--;
-				next = stk[sp][tid];
-			}
-			cur = next;
-		}
-		if (busy && cur < 0 && pend0 < 0) {
-			int id = found ? (ANYHIT ? 0 : best.rank) : -1;
-			hits[j] = make_float4(__int_as_float(id), best.t, best.alpha, best.beta);
-			busy = false;
-		}
-	}
-	if (STATS) {
-		// wave-level reduction, then one atomic per wave
-		for (int off = 32; off > 0; off >>= 1) {
-			nodeTests += __shfl_down(nodeTests, off, 64);
-			triTests += __shfl_down(triTests, off, 64);
-		}
-		if (lane == 0) {
-			atomicAdd(&stats[0], (unsigned long long)nodeTests);
-			atomicAdd(&stats[1], (unsigned long long)triTests);
-		}
-	}
-}
-
-// ------------------------------------------------------------------------------------------------
-// Wide traversal.
-//
-// For a ray whose three reciprocals 1/d are finite, every value the reference's slab test computes is
-// finite, and (bound - o) * (1/d) is monotone in `bound`.  A child box of the reference's tree lies
-// inside its parent's box exactly (both are min/max over vertex sets), so if the slab predicate
-// (src/BVH.cpp:14-41) passes for a leaf's own box it passes for every ancestor: for such rays the
-// candidate list of BVH::hit is exactly "the triangles whose own box passes".  The interior boxes only
-// prune, and any conservative bound may stand in for them.  This kernel therefore walks a 4-wide tree of
-// its own (rtx_wide.h) whose child boxes are quantised to 8 bits per coordinate inside the node's box,
-// rounded outwards, and tested inflated by the same position-space slack as the culling bounds.  Leaves
-// are tested with the exact predicate on their exact box (recomputed from the vertices) and the exact
-// Triangle::hit, and ties go to the reference's candidate order, so the result equals the reference's.
-//
-// A ray parallel to an axis (1/d = +-inf there) is walked here too.  On that axis the reference computes
-// +-inf, or NaN where the origin lies on a box plane.  Its folds over lanes 1 and 2 (y, z) skip a NaN, which
-// is the same as the unconstrained (-inf, +inf) a parent's wider slab gives, so the argument above still
-// holds.  A NaN in lane 0 (x) makes the reference accept the box whatever the other axes say, which a
-// parent need not do: a ray that meets that case at a leaf is set aside in a list for the binary-tree kernel
-// above, which evaluates every ancestor as the reference does; so are rays with a finite reciprocal beyond
-// 2^100 (whose products overflow) and rays that need more stack than this kernel has.  The quantised
-// tests are homogeneous in 1/d; they use +-2^100 in place of +-inf and so prune a parallel ray by
-// "origin inside the slab, give or take the slack".
-//
-// Node, 4 x 16 bytes:  px py pz sx                          (origin; sx, sy, sz: quantisation steps, powers of two)
-//                      lo.x[4] hi.x[4] lo.y[4] hi.y[4]      (one byte per child)
-//                      lo.z[4] hi.z[4] code0 code1
-//                      code2 code3 sy sz                       code > 0 node, < 0 ~rank, 0 absent
-constexpr float WIDE_MAX_INV = 1.2676506e30f;  // 2^100
-
-__device__ __forceinline__ float ubyte_f(unsigned v, int k) { return (float)((v >> (8 * k)) & 0xFFu); }
-
-template <int STACK, bool ANYHIT, bool STATS>
-__global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_trace_wide(DevScene sc, const float4* __restrict__ rayO,
-															   const float4* __restrict__ rayD, float4* __restrict__ hits,
-															   int n, unsigned long long* __restrict__ stats,
-															   unsigned* __restrict__ work, int* __restrict__ unsafeList,
-															   unsigned* __restrict__ unsafeCount, int refill, int chunk,
-															   int triBatch, const unsigned* __restrict__ nDev) {
-	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
-	__shared__ int stk[STACK][TRACE_THREADS];
-	const int tid = threadIdx.x;
-	const unsigned lane = (unsigned)tid & 63u;
-	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-	unsigned boxTests = 0, triTests = 0, nodeVisits = 0, leafFetches = 0;
-	unsigned walkIters = 0, leafIters = 0, walkLanes = 0, leafLanes = 0;  // wave-level, kept by lane 0
-	unsigned overflows = 0;
-	int cnext = 0, cend = 0;
-	bool more = true, firstChunk = true;
-	int j = -1, cur = -1, sp = 0;
-	RaySlab r;
-	r.ox = r.oy = r.oz = r.ix = r.iy = r.iz = r.mx = r.my = r.mz = 0.0f;
-	r.nx = r.ny = r.nz = false;
-	float dx = 0.0f, dy = 0.0f, dz = 0.0f;
-	float wix = 0.0f, wiy = 0.0f, wiz = 0.0f;  // 1/d as the interior tests use it: +-inf replaced by +-2^100
-	HitState best;
-	best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
-	bool found = false, busy = false;
-	int pend0 = -1, pend1 = -1;
-
-	for (;;) {
-		const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
-		const int nidle = __popcll(idle);
-		if (more && nidle >= refill) {
-			if (cnext >= cend) {
-				// A wave's first chunk is the one with its own number; later ones come from the shared cursor,
-				// which therefore starts behind those.  A launch over a short queue then costs no atomics at
-				// all (one address takes only ~90 of them per microsecond, and the grid has thousands of waves).
-				unsigned base = 0;
-				if (firstChunk) {
-					base = (blockIdx.x * (TRACE_THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6)) * (unsigned)chunk;
-					firstChunk = false;
-				}
-				else {
-					if (lane == 0) base = atomicAdd(work, (unsigned)chunk);
-					base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + gridDim.x * (TRACE_THREADS / 64) * (unsigned)chunk;
-				}
-				if (base >= (unsigned)n) {
-					more = false;
-					cnext = cend = 0;
-				}
-				else {
-					cnext = (int)base;
-					cend = min((int)base + chunk, n);
-				}
-			}
-			const int take = min(nidle, cend - cnext);
-			if (take > 0) {
-				const int slot = __popcll(idle & below);
-				if (!busy && slot < take) {
-					j = cnext + slot;
-					float4 O = rayO[j];
-					float4 D = rayD[j];
-					if (D.w != 0.0f) {
-						hits[j] = make_float4(__int_as_float(-2), FLT_MAX, 0.0f, 0.0f);
-					}
-					else {
-						r.ox = O.x; r.oy = O.y; r.oz = O.z;
-						dx = D.x; dy = D.y; dz = D.z;
-						r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
-						const bool zero = (dx == 0.0f) & (dy == 0.0f) & (dz == 0.0f);
-						const bool finite = (fabsf(dx) <= FLT_MAX) & (fabsf(dy) <= FLT_MAX) & (fabsf(dz) <= FLT_MAX) &
-											(r.ox == r.ox) & (r.oy == r.oy) & (r.oz == r.oz);
-						const float aix = fabsf(r.ix), aiy = fabsf(r.iy), aiz = fabsf(r.iz);
-						const bool safe = ((aix <= WIDE_MAX_INV) | (aix > FLT_MAX)) & ((aiy <= WIDE_MAX_INV) | (aiy > FLT_MAX)) &
-										  ((aiz <= WIDE_MAX_INV) | (aiz > FLT_MAX));
-						if (zero | !finite) {
-							// no triangle can accept such a ray (see k_trace)
-							hits[j] = make_float4(__int_as_float(-1), FLT_MAX, 0.0f, 0.0f);
-						}
-						else if (!safe) {
-							unsafeList[atomicAdd(unsafeCount, 1u)] = j;
-						}
-						else {
-							r.nx = (__float_as_uint(r.ix) >> 31) != 0;
-							r.ny = (__float_as_uint(r.iy) >> 31) != 0;
-							r.nz = (__float_as_uint(r.iz) >> 31) != 0;
-							// The interior tests are homogeneous in 1/d, so on an axis the ray is parallel to a large
-							// finite reciprocal decides "origin inside the slab, give or take the slack" just as well.
-							wix = aix > FLT_MAX ? copysignf(WIDE_MAX_INV, r.ix) : r.ix;
-							wiy = aiy > FLT_MAX ? copysignf(WIDE_MAX_INV, r.iy) : r.iy;
-							wiz = aiz > FLT_MAX ? copysignf(WIDE_MAX_INV, r.iz) : r.iz;
-							float scale = fmaxf(fmaxf(sc.sceneAbsMax, fabsf(r.ox)), fmaxf(fabsf(r.oy), fabsf(r.oz)));
-							float eps = scale * 6.103515625e-05f;
-							r.mx = eps * fabsf(wix); r.my = eps * fabsf(wiy); r.mz = eps * fabsf(wiz);
-							best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
-							found = false;
-							sp = 0;
-							cur = 0;
-							pend0 = pend1 = -1;
-							busy = true;
-						}
-					}
-				}
-				cnext += take;
-			}
-		}
-		// A lane walks while it has something to walk and a free leaf slot: a leaf it comes across is kept
-		// for later (two slots) and the walk goes on to what lies behind it.  That is speculative (the leaf
-		// may turn out to cut those nodes off) but keeps lanes out of the waiting room; the result does not
-		// depend on the order of the tests.
-		const bool canWalk = busy && pend1 < 0 && (cur >= 0 || sp > 0);
-		const unsigned long long mWalk = __builtin_amdgcn_ballot_w64(canWalk);
-		const unsigned long long mLeaf = __builtin_amdgcn_ballot_w64(busy && pend0 >= 0);
-		if (mWalk == 0ull && mLeaf == 0ull) {
-			if (!more) break;
-			continue;
-		}
-		const bool leafPhase = __popcll(mLeaf) >= triBatch || mWalk == 0ull;
-		if (STATS) {
-			if (leafPhase) {
-				leafIters++;
-				leafLanes += __popcll(mLeaf);
-			}
-			else {
-				walkIters++;
-				walkLanes += __popcll(mWalk);
-			}
-		}
-		if (leafPhase) {
-			// exact box of the triangle, exact slab predicate, exact triangle test; one leaf per lane and pass
-			if (busy && pend0 >= 0) {
-				const float4* T = sc.triHit + (size_t)pend0 * 4;
-				float4 q0 = T[0], q1 = T[1], q2 = T[2];
-				if (STATS) leafFetches++;
-				const float v0x = q0.w, v0y = q1.x, v0z = q1.y, v1x = q1.z, v1y = q1.w, v1z = q2.x, v2x = q2.y, v2y = q2.z, v2z = q2.w;
-				// the reference's predicate on the leaf's own box (src/BVH.cpp:14-41); lane 0 is never NaN here and
-				// fmaxf/fminf skip a NaN in lanes 1 and 2 as the reference's folds do
-				const float lx = fminf(fminf(v0x, v1x), v2x), hx = fmaxf(fmaxf(v0x, v1x), v2x);
-				const float ly = fminf(fminf(v0y, v1y), v2y), hy = fmaxf(fmaxf(v0y, v1y), v2y);
-				const float lz = fminf(fminf(v0z, v1z), v2z), hz = fmaxf(fmaxf(v0z, v1z), v2z);
-				const float t0x = (lx - r.ox) * r.ix, t1x = (hx - r.ox) * r.ix;
-				const float t0y = (ly - r.oy) * r.iy, t1y = (hy - r.oy) * r.iy;
-				const float t0z = (lz - r.oz) * r.iz, t1z = (hz - r.oz) * r.iz;
-				const float tmin = fmaxf(fmaxf(r.nx ? t1x : t0x, r.ny ? t1y : t0y), r.nz ? t1z : t0z);
-				const float tmax = fminf(fminf(r.nx ? t0x : t1x, r.ny ? t0y : t1y), r.nz ? t0z : t1z);
-				const bool pass = !(tmax < tmin);
-				if (STATS) boxTests++;
-				if (t0x != t0x || t1x != t1x) {
-					// The origin lies on an x plane of this box and the ray runs along it: the reference accepts
-					// such a box whatever y and z say (NaN in lane 0), provided it gets there, which only its own
-					// tree can tell.  The ray starts over in the binary-tree kernel.
-					unsafeList[atomicAdd(unsafeCount, 1u)] = j;
-					busy = false;
-					cur = -1;
-					sp = 0;
-					pend1 = -1;
-				}
-				else if (pass) {
-					if (STATS) triTests++;
-					found |= tri_test_vals(q0.x, q0.y, q0.z, v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z, pend0, r.ox, r.oy,
-										   r.oz, dx, dy, dz, best);
-				}
-				pend0 = pend1;
-				pend1 = -1;
-				if (ANYHIT && found) {
-					pend0 = -1;
-					cur = -1;
-					sp = 0;
-				}
-			}
-		}
-		else if (canWalk) {
-			int item = 0;  // what this lane looks at next: > 0 node, < 0 ~rank of a leaf, 0 nothing yet
-			if (cur >= 0) {
-				const float4* W = sc.wide + (size_t)cur * 4;
-				float4 w0 = W[0], w1 = W[1], w2 = W[2], w3 = W[3];
-				if (STATS) nodeVisits++;
-				const float Sx = w0.w * wix, Sy = w3.z * wiy, Sz = w3.w * wiz;
-				const float Ax = (w0.x - r.ox) * wix, Ay = (w0.y - r.oy) * wiy, Az = (w0.z - r.oz) * wiz;
-				const float Anx = Ax - r.mx, Any = Ay - r.my, Anz = Az - r.mz;
-				const float Afx = Ax + r.mx, Afy = Ay + r.my, Afz = Az + r.mz;
-				const unsigned lox = __float_as_uint(w1.x), hix = __float_as_uint(w1.y), loy = __float_as_uint(w1.z),
-							   hiy = __float_as_uint(w1.w), loz = __float_as_uint(w2.x), hiz = __float_as_uint(w2.y);
-				const unsigned nxd = r.nx ? hix : lox, fxd = r.nx ? lox : hix;
-				const unsigned nyd = r.ny ? hiy : loy, fyd = r.ny ? loy : hiy;
-				const unsigned nzd = r.nz ? hiz : loz, fzd = r.nz ? loz : hiz;
-				int cd[4] = {__float_as_int(w2.z), __float_as_int(w2.w), __float_as_int(w3.x), __float_as_int(w3.y)};
-				// key: ordered bits of what the children are sorted by, all ones for a child that is not entered
-				unsigned key[4];
-				int nh = 0;
-#pragma unroll
-				for (int c = 0; c < 4; ++c) {
-					float e = fmaxf(fmaxf(__fmaf_rn(ubyte_f(nxd, c), Sx, Anx), __fmaf_rn(ubyte_f(nyd, c), Sy, Any)),
-									__fmaf_rn(ubyte_f(nzd, c), Sz, Anz));
-					float x = fminf(fminf(__fmaf_rn(ubyte_f(fxd, c), Sx, Afx), __fmaf_rn(ubyte_f(fyd, c), Sy, Afy)),
-									__fmaf_rn(ubyte_f(fzd, c), Sz, Afz));
-					e = fmaxf(e, 0.001f);
-					const bool h = (cd[c] != 0) & !(x < e) & !(e > best.t);
-					// closest hit: nearest child first.  Any hit: the child the ray stays in longest first, where an
-					// occluder is likeliest (any order gives the same answer; the key stays below the "not
-					// entered" marker because the length is clamped to >= +0).
-					key[c] = !h ? 0xFFFFFFFFu : ANYHIT ? 0x7FFFFFFFu - __float_as_uint(fmaxf(x - e, 0.0f)) : __float_as_uint(e);
-					nh += h ? 1 : 0;
-					if (STATS) boxTests += cd[c] != 0;
-				}
-				// sorting network on (key, code), nearest first
-#define RTX_CSWAP(i, j)                                     \
-	{                                                       \
-		const bool sw = key[i] > key[j];                    \
-		const unsigned klo = min(key[i], key[j]);           \
-		const unsigned khi = max(key[i], key[j]);           \
-		const int ci = sw ? cd[j] : cd[i];                  \
-		const int cj = sw ? cd[i] : cd[j];                  \
-		key[i] = klo; key[j] = khi; cd[i] = ci; cd[j] = cj; \
-	}
-				RTX_CSWAP(0, 1)
-				RTX_CSWAP(2, 3)
-				RTX_CSWAP(0, 2)
-				RTX_CSWAP(1, 3)
-				RTX_CSWAP(1, 2)
-#undef RTX_CSWAP
-				// the nearest is looked at next, the others wait with the farthest at the bottom
-				if (sp + nh - 1 > STACK) {
-					// no room: the ray starts over in the binary-tree kernel, whose stack covers its whole tree
-					unsafeList[atomicAdd(unsafeCount, 1u)] = j;
-					if (STATS) overflows++;
-					busy = false;
-					sp = 0;
-					nh = 0;
-					pend0 = -1;
-				}
-				if (nh > 3) stk[sp][tid] = cd[3];
-				if (nh > 2) stk[sp + nh - 3][tid] = cd[2];
-				if (nh > 1) stk[sp + nh - 2][tid] = cd[1];
-				sp += max(nh - 1, 0);
-				item = nh > 0 ? cd[0] : 0;
-				cur = -1;
-			}
-			if (item == 0 && sp > 0) {
-				sp--;
-				item = stk[sp][tid];
-			}
-			if (item < 0) {
-				// a leaf: keep it and look at what comes after it
-				if (pend0 < 0) pend0 = ~item;
-				else pend1 = ~item;
-				item = 0;
-				if (pend1 < 0 && sp > 0) {
-					sp--;
-					item = stk[sp][tid];
-					if (item < 0) {
-						pend1 = ~item;
-						item = 0;
-					}
-				}
-			}
-			if (item > 0) cur = item;
-		}
-		if (busy && cur < 0 && pend0 < 0 && sp == 0) {
-			int id = found ? (ANYHIT ? 0 : best.rank) : -1;
-			hits[j] = make_float4(__int_as_float(id), best.t, best.alpha, best.beta);
-			busy = false;
-		}
-	}
-	if (STATS) {
-		for (int off = 32; off > 0; off >>= 1) {
-			boxTests += __shfl_down(boxTests, off, 64);
-			triTests += __shfl_down(triTests, off, 64);
-			nodeVisits += __shfl_down(nodeVisits, off, 64);
-			leafFetches += __shfl_down(leafFetches, off, 64);
-		}
-		if (lane == 0) {
-			atomicAdd(&stats[0], (unsigned long long)boxTests);
-			atomicAdd(&stats[1], (unsigned long long)triTests);
-			atomicAdd(&stats[4], (unsigned long long)nodeVisits);
-			atomicAdd(&stats[5], (unsigned long long)leafFetches);
-			atomicAdd(&stats[2], (unsigned long long)walkIters);
-			atomicAdd(&stats[3], (unsigned long long)walkLanes);
-			atomicAdd(&stats[6], (unsigned long long)leafIters);
-			atomicAdd(&stats[7], (unsigned long long)leafLanes);
-		}
-		for (int off = 32; off > 0; off >>= 1) overflows += __shfl_down(overflows, off, 64);
-		if (lane == 0) {
-			atomicAdd(&stats[8], (unsigned long long)overflows);
-		}
-	}
-}
-
-// ------------------------------------------------------------------------------------------------
-// Shade.  One thread per ray of level `level`.  Writes the path-node record of this ray:
-//   A[j]  leaf: its radiance.   interior: triangle colour (replaced by the node's radiance in k_gather)
-//   B[j]  (first child slot, kind | flags, scalar as float bits, -)   scalar = |n.d| (dielectric) or
-//         the refracted proportion (transparent)
-//   C[j]  texel of a textured dielectric
-// and appends the node's child rays to the next level's queue.  cnt[0] receives the queue
-// length, cnt[1] dead slots (refraction under total internal reflection), cnt[2] shaded hits,
-// cnt[3] texel fetches.
-
-__device__ __forceinline__ void scatter_offset(const DevScene& sc, uint32_t key, uint32_t lobe, uint32_t k, float& ox,
-											   float& oy, float& oz) {
-	uint32_t phi = rt_draw(key, lobe, k, 0) & 0x1FFu;
-	uint32_t theta = (rt_draw(key, lobe, k, 1) & 0x1FFu) >> 1;
-	float cp = sc.cosT[phi], sp = sc.sinT[phi], ct = sc.cosT[theta], st = sc.sinT[theta];
-	// horizontal * sin(theta) + cos(theta) * UnitZ, lane by lane (src/Triangle.cpp:107-113)
-	ox = cp * st + ct * 0.0f;
-	oy = sp * st + ct * 0.0f;
-	oz = 0.0f * st + ct * 1.0f;
-}
-
-constexpr int SHADE_THREADS = 1024;  // 16 waves share one queue-tail atomic
-
-__global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level, const float4* __restrict__ rayO,
-											   const float4* __restrict__ rayD, const float4* __restrict__ hits, int n,
-											   float4* __restrict__ A, int4* __restrict__ B, float4* __restrict__ C,
-											   float4* __restrict__ nRayO, float4* __restrict__ nRayD,
-											   unsigned* __restrict__ cnt, unsigned nextCap, const unsigned* __restrict__ nDev) {
-	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
-	__shared__ unsigned s_tot[SHADE_THREADS / 64];
-	__shared__ unsigned s_base[SHADE_THREADS / 64];
-	__shared__ unsigned s_stat[3][SHADE_THREADS / 64];
-	// The grid does not grow with the queue: a block walks over it in steps of the grid's width (every thread
-	// of a block makes the same number of rounds, so the barriers below are uniform).
-	for (long long base = (long long)blockIdx.x * SHADE_THREADS; base < n; base += (long long)gridDim.x * SHADE_THREADS) {
-		const int j = (int)base + (int)threadIdx.x;
-		const int S = sc.nSpec, Dn = sc.nDiff;
-		int kind = KIND_LEAF;
-		int flags = 0;
-		int nchild = 0;
-		float3 val = make_float3(0.0f, 0.0f, 0.0f);
-		float scalar = 0.0f;
-		float3 texel = make_float3(0.0f, 0.0f, 0.0f);
-		// state needed after the allocation
-		float hx = 0, hy = 0, hz = 0, nx = 0, ny = 0, nz = 0, dx = 0, dy = 0, dz = 0, rough = 0, ior = 1;
-		uint32_t key = 0;
-		unsigned dead = 0, shaded = 0, fetches = 0;
-		const bool active = j < n;
-		if (active) {
-			float4 O = rayO[j];
-			float4 D = rayD[j];
-			float4 H = hits[j];
-			int rank = __float_as_int(H.x);
-			key = __float_as_uint(O.w);
-			dx = D.x; dy = D.y; dz = D.z;
-			if (rank == -2) {
-				dead = 1;
-			}
-			else if (rank == -1) {
-				if (sc.hasSky) {
-					val = sky_fetch(sc, dx, dy, dz);
-					fetches = 1;
-				}
-				else
-					val = make_float3(sc.bg.x, sc.bg.y, sc.bg.z);
-			}
-			else if (level < sc.maxDepth) {
-				// (at level == maxDepth every hit returns zero, src/RayTracer.cpp:170; the any-hit
-				//  traversal reports such hits with rank 0, which is never dereferenced)
-				// one aligned 64-byte record serves every hit; the texture coordinates live apart
-				const float4* T = sc.triShade + (size_t)rank * 4;
-				float4 s0 = T[0], s1 = T[1], s2 = T[2], s3 = T[3];
-				const float t = H.y, alpha = H.z, beta = H.w;
-				const int triFlags = __float_as_int(s3.w);
-				const int texId = __float_as_int(s3.z);
-				hx = O.x + t * dx;
-				hy = O.y + t * dy;
-				hz = O.z + t * dz;
-				float g = 1.0f - (alpha + beta);
-				nx = (alpha * s0.x + beta * s1.x) + g * s2.x;
-				ny = (alpha * s0.y + beta * s1.y) + g * s2.y;
-				nz = (alpha * s0.z + beta * s1.z) + g * s2.z;
-				float z = dot3w(nx, ny, nz, nx, ny, nz);
-				if (z > 0.0f) {
-					float len = sqrtf(z);
-					nx = nx / len;
-					ny = ny / len;
-					nz = nz / len;
-				}
-				float cosine = dot3w(nx, ny, nz, dx, dy, dz);
-				const bool transp = (triFlags & TRI_TRANSP) != 0;
-				if (!transp && cosine >= 0.0f) {
-					// back side: zero
-				}
-				else if (triFlags & TRI_EMIT) {
-					val = make_float3(s0.w, s1.w, s2.w);
-				}
-				else {
-					shaded = 1;
-					val = make_float3(s0.w, s1.w, s2.w);  // colour, consumed by k_gather
-					rough = s3.x;
-					ior = s3.y;
-					if (triFlags & TRI_METAL) {
-						kind = KIND_METAL;
-						nchild = S;
-					}
-					else if (transp) {
-						kind = KIND_TRANSP;
-						nchild = S + 1;
-					}
-					else {
-						kind = KIND_DIEL;
-						nchild = S + Dn;
-						scalar = fabsf(cosine);
-						if (texId >= 0) {
-							flags |= FLAG_TEX;
-							const float4 u01 = sc.triUv[(size_t)rank * 2], u2 = sc.triUv[(size_t)rank * 2 + 1];
-							float u = (alpha * u01.x + beta * u01.z) + g * u2.x;
-							float v = (alpha * u01.y + beta * u01.w) + g * u2.y;
-							texel = tex_fetch(sc, texId, u, v);
-							fetches = 1;
-						}
-					}
-				}
-			}
-		}
-
-		// ---- queue slots for the children.  Inside a wave, per-kind ballots + popcounts give each lane its
-		// offset; the 16 wave totals of the block are scanned in LDS and the block claims its range of the
-		// next level's queue with a single atomic (one word takes only ~90 atomics per microsecond, so one
-		// atomic per wave would bound the kernel).
-		const unsigned lane = threadIdx.x & 63;
-		const unsigned wave = threadIdx.x >> 6;
-		const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-		unsigned long long bm = __ballot(kind == KIND_METAL);
-		unsigned long long bt = __ballot(kind == KIND_TRANSP);
-		unsigned long long bd = __ballot(kind == KIND_DIEL);
-		unsigned offset = (unsigned)__popcll(bm & lt) * (unsigned)S + (unsigned)__popcll(bt & lt) * (unsigned)(S + 1) +
-						  (unsigned)__popcll(bd & lt) * (unsigned)(S + Dn);
-		unsigned total = (unsigned)__popcll(bm) * (unsigned)S + (unsigned)__popcll(bt) * (unsigned)(S + 1) +
-						 (unsigned)__popcll(bd) * (unsigned)(S + Dn);
-		unsigned long long bdead = __ballot(dead != 0), bsh = __ballot(shaded != 0), bf = __ballot(fetches != 0);
-		if (lane == 0) {
-			s_tot[wave] = total;
-			s_stat[0][wave] = (unsigned)__popcll(bdead);
-			s_stat[1][wave] = (unsigned)__popcll(bsh);
-			s_stat[2][wave] = (unsigned)__popcll(bf);
-		}
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			unsigned run = 0, d = 0, sh = 0, f = 0;
-			for (int w = 0; w < SHADE_THREADS / 64; ++w) {
-				s_base[w] = run;
-				run += s_tot[w];
-				d += s_stat[0][w];
-				sh += s_stat[1][w];
-				f += s_stat[2][w];
-			}
-			unsigned base = run ? atomicAdd(&cnt[0], run) : 0u;
-			for (int w = 0; w < SHADE_THREADS / 64; ++w) s_base[w] += base;
-			if (d) atomicAdd(&cnt[1], d);
-			if (sh) atomicAdd(&cnt[2], sh);
-			if (f) atomicAdd(&cnt[3], f);
-		}
-		__syncthreads();
-		const unsigned childBase = s_base[wave] + offset;
-
-		if (nchild) {
-			if (childBase + (unsigned)nchild > nextCap) {
-				// cannot happen when the host sized the queue for the worst case; drop the subtree
-				kind = KIND_LEAF;
-				val = make_float3(0.0f, 0.0f, 0.0f);
-				nchild = 0;
-				atomicOr(&cnt[4], 1u);
-			}
-		}
-		if (nchild) {
-			// Triangle::specular (src/Triangle.cpp:121-146)
-			float np = dot3w(dx, dy, dz, nx, ny, nz);
-			float k2 = 2.0f * np;
-			float rx = dx - k2 * nx, ry = dy - k2 * ny, rz = dz - k2 * nz;
-			for (int i = 0; i < S; ++i) {
-				float ox, oy, oz;
-				scatter_offset(sc, key, 0, (uint32_t)i, ox, oy, oz);
-				float cx = rx + ox * rough, cy = ry + oy * rough, cz = rz + oz * rough;
-				nRayO[childBase + i] = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)i)));
-				nRayD[childBase + i] = make_float4(cx, cy, cz, 0.0f);
-			}
-			if (kind == KIND_DIEL) {
-				// Triangle::diffuse (src/Triangle.cpp:95-119)
-				bool keep = dot3w(dx, dy, dz, nx, ny, nz) < 0.0f;
-				float tx = keep ? nx : -nx, ty = keep ? ny : -ny, tz = keep ? nz : -nz;
-				for (int i = 0; i < Dn; ++i) {
-					float ox, oy, oz;
-					scatter_offset(sc, key, 1, (uint32_t)i, ox, oy, oz);
-					nRayO[childBase + S + i] = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)(S + i))));
-					nRayD[childBase + S + i] = make_float4(tx + ox, ty + oy, tz + oz, 0.0f);
-				}
-			}
-			else if (kind == KIND_TRANSP) {
-				// Triangle::refract (src/Triangle.cpp:149-179)
-				float dot = dot3w(dx, dy, dz, nx, ny, nz);
-				float indexRatio = dot > 0.0f ? ior : (1.0f / ior);
-				float tx = dot > 0.0f ? -nx : nx, ty = dot > 0.0f ? -ny : ny, tz = dot > 0.0f ? -nz : nz;
-				float cosineTheta = fabsf(dot);
-				float squareSine1 = 1.0f - cosineTheta * cosineTheta;
-				float squareSine2 = (indexRatio * indexRatio) * squareSine1;
-				float4 ro = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)S)));
-				if (squareSine2 > 1.0f) {
-					// total internal reflection: proportion 0, child not traced
-					flags |= FLAG_TIR;
-					scalar = 0.0f;
-					nRayO[childBase + S] = ro;
-					nRayD[childBase + S] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-				}
-				else {
-					float cosine2 = sqrtf(1.0f - squareSine2);
-					float ex = indexRatio * (dx + cosineTheta * tx) - tx * cosine2;
-					float ey = indexRatio * (dy + cosineTheta * ty) - ty * cosine2;
-					float ez = indexRatio * (dz + cosineTheta * tz) - tz * cosine2;
-					float temp = (1.0f - indexRatio) / (1.0f + indexRatio);
-					float r0 = temp * temp;
-					float squareTemp = (1.0f - cosineTheta) * (1.0f - cosineTheta);
-					float pow5 = squareTemp * squareTemp * (1.0f - cosineTheta);
-					float reflectProportion = r0 + (1.0f - r0) * pow5;
-					scalar = 1.0f - reflectProportion;
-					nRayO[childBase + S] = ro;
-					nRayD[childBase + S] = make_float4(ex, ey, ez, 0.0f);
-				}
-			}
-		}
-		if (active) {
-			A[j] = make_float4(val.x, val.y, val.z, 0.0f);
-			B[j] = make_int4((int)childBase, kind | flags, __float_as_int(scalar), 0);
-			if (flags & FLAG_TEX) C[j] = make_float4(texel.x, texel.y, texel.z, 0.0f);
-		}
-		__syncthreads();  // the LDS words are reused by the next round
-	}
-}
-
-// The rays of the last recursion level end their paths whatever they hit: a hit returns zero
-// (src/RayTracer.cpp:170), a miss the sky or the background (:148-152).  Only A is written (B and C of the
-// last level are never read).  Blocks stride over the queue so that each adds its counts once.
-__global__ __launch_bounds__(256) void k_shade_last(DevScene sc, const float4* __restrict__ rayD, const float4* __restrict__ hits,
-													int n, float4* __restrict__ A, unsigned* __restrict__ cnt, const unsigned* __restrict__ nDev) {
-	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
-	unsigned dead = 0, fetches = 0;
-	for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
-		const int rank = __float_as_int(hits[j].x);
-		float3 val = make_float3(0.0f, 0.0f, 0.0f);
-		if (rank == -2) dead++;
-		else if (rank == -1) {
-			if (sc.hasSky) {
-				const float4 D = rayD[j];
-				val = sky_fetch(sc, D.x, D.y, D.z);
-				fetches++;
-			}
-			else
-				val = make_float3(sc.bg.x, sc.bg.y, sc.bg.z);
-		}
-		A[j] = make_float4(val.x, val.y, val.z, 0.0f);
-	}
-	for (int off = 32; off > 0; off >>= 1) {
-		dead += __shfl_down(dead, off, 64);
-		fetches += __shfl_down(fetches, off, 64);
-	}
-	if ((threadIdx.x & 63) == 0) {
-		if (dead) atomicAdd(&cnt[1], dead);
-		if (fetches) atomicAdd(&cnt[3], fetches);
-	}
-}
-
-// Combine step of RayTracer::color for the nodes of one level, children read from the next
-// level (src/RayTracer.cpp:177-224).  Sums start from zero and run in child order, scale
-// factors are applied after the sum, exactly as the reference does.
-__global__ __launch_bounds__(256) void k_gather(int S, int Dn, int n, float4* __restrict__ A,
-												const int4* __restrict__ B, const float4* __restrict__ C,
-												const float4* __restrict__ childA, const unsigned* __restrict__ nDev) {
-	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
-	for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
-		int4 b = B[j];
-		const int kind = b.y & 0xFF;
-		if (kind == KIND_LEAF) continue;
-		const float4 col = A[j];
-		const float4* ch = childA + (unsigned)b.x;
-		float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-		for (int i = 0; i < S; ++i) {
-			float4 c = ch[i];
-			sx = sx + c.x;
-			sy = sy + c.y;
-			sz = sz + c.z;
-		}
-		const float fS = (float)S;
-		float ox, oy, oz;
-		if (kind == KIND_METAL) {
-			ox = (sx * col.x) / fS;
-			oy = (sy * col.y) / fS;
-			oz = (sz * col.z) / fS;
-		}
-		else if (kind == KIND_TRANSP) {
-			sx = sx / fS;
-			sy = sy / fS;
-			sz = sz / fS;
-			const float rp = __int_as_float(b.z);
-			float4 rc = (b.y & FLAG_TIR) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : ch[S];
-			const float q = 1.0f - rp;
-			ox = rp * rc.x + q * sx;
-			oy = rp * rc.y + q * sy;
-			oz = rp * rc.z + q * sz;
-		}
-		else {
-			const float w = 0.04f / fS;
-			sx = sx * w;
-			sy = sy * w;
-			sz = sz * w;
-			float dx = 0.0f, dy = 0.0f, dz = 0.0f;
-			for (int i = 0; i < Dn; ++i) {
-				float4 c = ch[S + i];
-				dx = dx + c.x;
-				dy = dy + c.y;
-				dz = dz + c.z;
-			}
-			const float fD = (float)Dn;
-			dx = (dx * col.x) / fD;
-			dy = (dy * col.y) / fD;
-			dz = (dz * col.z) / fD;
-			const float ad = __int_as_float(b.z);
-			ox = sx + dx * ad;
-			oy = sy + dy * ad;
-			oz = sz + dz * ad;
-			if (b.y & FLAG_TEX) {
-				float4 tx = C[j];
-				ox = ox * tx.x;
-				oy = oy * tx.y;
-				oz = oz * tx.z;
-			}
-		}
-		A[j] = make_float4(ox, oy, oz, 0.0f);
-	}
-}
-
-// accumulateImg(row,col) += (c0+c1+c2+c3) * 0.25f (src/RayTracer.cpp:242-246).  One thread per pixel.
-// True when some level's child queue was too small for this batch (slot 4 of the counter blocks): the batch's
-// result is then incomplete, is not stored, and the host renders the batch again with worst-case queues.
-__device__ __forceinline__ bool batch_overflowed(const unsigned* __restrict__ counts, int maxDepth) {
-	unsigned f = 0;
-	for (int lv = 1; lv <= maxDepth + 1; ++lv) f |= counts[lv * 8 + 4];
-	return f != 0;
-}
-
-__global__ __launch_bounds__(256) void k_accumulate(DevScene sc, Batch b, const float4* __restrict__ A,
-													float4* __restrict__ accum, const unsigned* __restrict__ counts) {
-	if (batch_overflowed(counts, sc.maxDepth)) return;
-	const int p = blockIdx.x * 256 + threadIdx.x;
-	if (p * 4 >= b.nSamples) return;
-	int x, y, sub;
-	if (!sample_to_pixel(sc, b, p * 4, x, y, sub)) return;
-	float tx = 0.0f, ty = 0.0f, tz = 0.0f;
-	for (int k = 0; k < 4; ++k) {
-		float4 c = A[p * 4 + k];
-		tx = tx + c.x;
-		ty = ty + c.y;
-		tz = tz + c.z;
-	}
-	float4* dst = accum + ((size_t)y * sc.width + x);
-	float4 a = *dst;
-	a.x = a.x + tx * 0.25f;
-	a.y = a.y + ty * 0.25f;
-	a.z = a.z + tz * 0.25f;
-	a.w = a.w + 0.0f * 0.25f;
-	*dst = a;
-}
-
-// out8 = clamp(lroundf(powf(acc / frame, 1 / 2.2f) * 255)) (src/RayTracer.cpp:248-257) as a table search: the
-// bytes of the step function were tabulated with the host's own libm, `bits` are the float bit patterns at
-// which it steps (ascending, bits[0] = 0).  One thread per four pixels = three packed words of output.
-constexpr int TONE_MAX = 1024;
-__global__ __launch_bounds__(256) void k_tonemap(const float4* __restrict__ accum, int npix, float frame,
-												 const unsigned* __restrict__ bits, const unsigned char* __restrict__ values, int n,
-												 unsigned negative, unsigned nan, unsigned char* __restrict__ rgb8) {
-	__shared__ unsigned sBits[TONE_MAX];
-	__shared__ unsigned char sVal[TONE_MAX];
-	for (int i = threadIdx.x; i < n; i += 256) {
-		sBits[i] = bits[i];
-		sVal[i] = values[i];
-	}
-	__syncthreads();
-	const int p0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-	if (p0 >= npix) return;
-	unsigned char out[12];
-#pragma unroll
-	for (int k = 0; k < 4; ++k) {
-		float4 a = p0 + k < npix ? accum[p0 + k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-		const float ch[3] = {a.x / frame, a.y / frame, a.z / frame};
-#pragma unroll
-		for (int c = 0; c < 3; ++c) {
-			const unsigned b = __float_as_uint(ch[c]);
-			unsigned v;
-			if (ch[c] != ch[c]) v = nan;
-			else if (b >> 31) v = negative;
-			else {
-				int lo = 0, hi = n;  // last i with sBits[i] <= b
-				while (hi - lo > 1) {
-					const int mid = (lo + hi) >> 1;
-					if (sBits[mid] <= b) lo = mid;
-					else hi = mid;
-				}
-				v = sVal[lo];
-			}
-			out[k * 3 + c] = (unsigned char)v;
-		}
-	}
-	if (p0 + 4 <= npix) {
-		unsigned w[3];
-#pragma unroll
-		for (int i = 0; i < 3; ++i)
-			w[i] = (unsigned)out[i * 4] | ((unsigned)out[i * 4 + 1] << 8) | ((unsigned)out[i * 4 + 2] << 16) | ((unsigned)out[i * 4 + 3] << 24);
-		unsigned* dst = (unsigned*)(rgb8 + (size_t)p0 * 3);  // p0 is a multiple of 4: 12-byte stride, 4-byte aligned
-		dst[0] = w[0];
-		dst[1] = w[1];
-		dst[2] = w[2];
-	}
-	else {
-		for (int i = 0; i < (npix - p0) * 3; ++i) rgb8[(size_t)p0 * 3 + i] = out[i];
-	}
-}
-
-// Per-sample radiance export (rtx_sample_radiance): out[(y*W+x)*4+sub] = A[j].
-__global__ __launch_bounds__(256) void k_export_samples(DevScene sc, Batch b, const float4* __restrict__ A,
-														float4* __restrict__ out, const unsigned* __restrict__ counts) {
-	if (batch_overflowed(counts, sc.maxDepth)) return;
-	const int j = blockIdx.x * 256 + threadIdx.x;
-	if (j >= b.nSamples) return;
-	int x, y, sub;
-	if (!sample_to_pixel(sc, b, j, x, y, sub)) return;
-	out[((size_t)y * sc.width + x) * 4 + sub] = A[j];
-}
-
-// Primary-hit export: rank -> reference triangle index.
-__global__ __launch_bounds__(256) void k_export_hits(DevScene sc, Batch b, const float4* __restrict__ hits,
-													 int* __restrict__ ids, float* __restrict__ tab) {
-	const int j = blockIdx.x * 256 + threadIdx.x;
-	if (j >= b.nSamples) return;
-	int x, y, sub;
-	if (!sample_to_pixel(sc, b, j, x, y, sub)) return;
-	float4 h = hits[j];
-	int rank = __float_as_int(h.x);
-	size_t o = ((size_t)y * sc.width + x) * 4 + sub;
-	ids[o] = rank >= 0 ? __float_as_int(sc.triHit[(size_t)rank * 4 + 3].x) : -1;
-	if (tab) {
-		tab[o * 3 + 0] = h.y;
-		tab[o * 3 + 1] = h.z;
-		tab[o * 3 + 2] = h.w;
-	}
-}
-
-__global__ __launch_bounds__(256) void k_export_hits_linear(DevScene sc, int n, const float4* __restrict__ hits,
-															int* __restrict__ ids, float* __restrict__ tab) {
-	const int j = blockIdx.x * 256 + threadIdx.x;
-	if (j >= n) return;
-	float4 h = hits[j];
-	int rank = __float_as_int(h.x);
-	ids[j] = rank >= 0 ? __float_as_int(sc.triHit[(size_t)rank * 4 + 3].x) : -1;
-	if (tab) {
-		tab[(size_t)j * 3 + 0] = h.y;
-		tab[(size_t)j * 3 + 1] = h.z;
-		tab[(size_t)j * 3 + 2] = h.w;
-	}
-}
+namespace {
 
 // ------------------------------------------------------------------------------------------------
 // Host side of the library.
