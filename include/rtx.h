@@ -201,6 +201,11 @@ int rtxh_tonemap(const float* accum_rgba, int frame, size_t npix, uint8_t* rgb8)
  * inputs, special[1] = byte for NaN. */
 int rtxh_tonemap_table(uint32_t* bits, uint8_t* values, int cap, int* n_out, uint8_t special[2]);
 
+/* Texture::Texture(path) (src/Texture.cpp:4-8): decodes an image file (JPEG, PNG, BMP, TGA, PPM/PGM) to 8-bit RGB,
+ * bottom row first as the reference keeps it.  Writes width and height; copies the pixels when `rgb` is not
+ * null and `capacity` >= width*height*3.  Returns the byte count needed, or a negative rtx_status. */
+long long rtxh_load_texture(const char* path, int* width, int* height, uint8_t* rgb, size_t capacity);
+
 /* Whole drop-in: parse `config_path` with the grammar of RayTracer::parseConfigFile
  * (src/RayTracer.cpp:284-518), render on `n_devices` GPUs (device ids 0..n-1) and write
  * out_%03d.png into `out_dir` after every frame like src/RayTracer.cpp:263-271.

@@ -328,6 +328,7 @@ class Reference(_Base):
         self._add_triangle_cfg = L._fn("add_triangle_cfg", None, _vp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _f, _f)
         self._add_texture_file = L._fn("add_texture_file", _i, _vp, C.c_char_p)
         self._load_skybox = L._fn("load_skybox", _i, _vp, _f, *([C.c_char_p] * 6))
+        self._texture_pixels = L._fn("texture_pixels", C.c_longlong, C.c_char_p, _ip, _ip, _vp, C.c_size_t)
         self._sample_texture = L._fn("sample_texture", None, _vp, _i, _f, _f, _fp)
         self._sample_sky = L._fn("sample_sky", None, _vp, _fp, _fp)
         self._build_bvh = L._fn("build_bvh", _i, _vp)
@@ -355,6 +356,17 @@ class Reference(_Base):
             self.close()
         except Exception:
             pass
+
+    def texture_pixels(self, path):
+        """What Texture::Texture(path) holds after the reference's stb_image decoded the file: (H, W, 3) uint8,
+        bottom row first; None when the reference cannot load it."""
+        w, h = C.c_int(0), C.c_int(0)
+        n = self._texture_pixels(os.fsencode(path), C.byref(w), C.byref(h), None, 0)
+        if n < 0:
+            return None
+        out = np.zeros(n, np.uint8)
+        self._texture_pixels(os.fsencode(path), C.byref(w), C.byref(h), out.ctypes.data, n)
+        return out.reshape(h.value, w.value, 3)
 
     def set_params(self, width, height, max_depth, n_diff, n_spec, bg=(0, 0, 0), seed=0):
         self.width, self.height = width, height

@@ -138,6 +138,19 @@ REF_API int ref_add_texture_file(void* h, const char* path) {
 	return (int)t->texturesArray.size() - 1;
 }
 
+// The pixels Texture::Texture(path) (src/Texture.cpp:4-8) decoded through the reference's stb_image: writes
+// width and height, copies width*height*3 bytes when they fit.  Returns the byte count, or -1.
+REF_API long long ref_texture_pixels(const char* path, int* width, int* height, unsigned char* out, size_t capacity) {
+	Texture tex(path);
+	if (!tex.hasTexture()) return -1;
+	const int w = tex.width, h = (int)tex.vMaxIndex + 1;
+	*width = w;
+	*height = h;
+	const size_t n = (size_t)w * h * 3;
+	if (out && capacity >= n) std::memcpy(out, tex.data, n);
+	return (long long)n;
+}
+
 // Skybox::load (src/Skybox.cpp:4). Returns 1 when all six faces loaded.
 REF_API int ref_load_skybox(void* h, float brightness, const char* front, const char* back, const char* left,
 							const char* right, const char* top, const char* bottom) {

@@ -77,6 +77,7 @@ HOST_SYMBOLS = {
     "rtxh_tables": (_i, [_fp, _fp, _fp]),
     "rtxh_tonemap": (_i, [_fp, _i, C.c_size_t, _vp]),
     "rtxh_tonemap_table": (_i, [_vp, _vp, _i, _ip, _vp]),
+    "rtxh_load_texture": (C.c_longlong, [C.c_char_p, _ip, _ip, _vp, C.c_size_t]),
     "rtxh_run_config": (_i, [C.c_char_p, C.c_char_p, _i]),
 }
 
@@ -177,6 +178,15 @@ def tonemap(accum, frame):
     out = np.zeros((npix, 3), np.uint8)
     _chkh(host_lib().rtxh_tonemap(_p(accum.reshape(-1)), frame, npix, out.ctypes.data))
     return out
+
+
+def load_texture(path):
+    """Texture::Texture(path): (H, W, 3) uint8, bottom row first."""
+    w, h = C.c_int(0), C.c_int(0)
+    need = _chkh(host_lib().rtxh_load_texture(os.fsencode(path), C.byref(w), C.byref(h), None, 0))
+    out = np.zeros(need, np.uint8)
+    _chkh(host_lib().rtxh_load_texture(os.fsencode(path), C.byref(w), C.byref(h), out.ctypes.data, need))
+    return out.reshape(h.value, w.value, 3)
 
 
 def tonemap_table():

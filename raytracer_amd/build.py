@@ -16,7 +16,7 @@ HOST_SO = os.path.join(PKG, "librtx_host.so")
 CLI_BIN = os.path.join(PKG, "RayTracer")
 
 HIP_SOURCES = ["rtx_hip.hip"]
-HOST_SOURCES = ["rtx_host.cpp", "rtx_config.cpp", "rtx_image.cpp"]
+HOST_SOURCES = ["rtx_host.cpp", "rtx_config.cpp", "rtx_image.cpp", "rtx_jpeg.cpp"]
 HIP_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
              "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-fvisibility=hidden"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-mavx2", "-mfma", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wextra"]
@@ -50,7 +50,7 @@ def build_hip(force=False, verbose=False):
 
 def build_host(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, "rtx_host_internal.h"), os.path.join(PKG, "..", "include", "rtx.h")]
+    deps = srcs + [os.path.join(CSRC, "rtx_host_internal.h"), os.path.join(CSRC, "rtx_image.h"), os.path.join(PKG, "..", "include", "rtx.h")]
     if not force and _newer(HOST_SO, deps):
         return HOST_SO
     cmd = ["g++"] + HOST_FLAGS + ["-shared"] + srcs + ["-o", HOST_SO, "-lpthread", "-ldl"]

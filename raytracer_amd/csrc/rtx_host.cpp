@@ -21,6 +21,7 @@
 
 #include "../../include/rtx.h"
 #include "rtx_host_internal.h"
+#include "rtx_image.h"
 
 #define RTXH_API extern "C" __attribute__((visibility("default")))
 
@@ -457,6 +458,16 @@ RTXH_API int rtxh_tables(float cos512[512], float sin512[512], float gamma256[25
 	if (!cos512 || !sin512 || !gamma256) return fail(RTX_ERR_ARG, "null argument");
 	tables(cos512, sin512, gamma256);
 	return RTX_OK;
+}
+
+RTXH_API long long rtxh_load_texture(const char* path, int* width, int* height, uint8_t* rgb, size_t capacity) {
+	if (!path || !width || !height) return fail(RTX_ERR_ARG, "null argument");
+	Image img;
+	if (!load_texture_file(path, img)) return fail(RTX_ERR_ARG, std::string("Can't load texture in ") + path);
+	*width = img.w;
+	*height = img.h;
+	if (rgb && capacity >= img.rgb.size()) std::memcpy(rgb, img.rgb.data(), img.rgb.size());
+	return (long long)img.rgb.size();
 }
 
 RTXH_API int rtxh_tonemap_table(uint32_t* bits, uint8_t* values, int cap, int* n_out, uint8_t special[2]) {

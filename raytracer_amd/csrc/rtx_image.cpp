@@ -1,5 +1,5 @@
 // Image file I/O for the host side: 8-bit RGB texture loading (binary PPM/PGM, 24/32-bit BMP,
-// uncompressed or RLE TGA, non-interlaced 8-bit PNG) with the reference's vertical flip
+// uncompressed or RLE TGA, non-interlaced 8-bit PNG, JPEG via rtx_jpeg.cpp) with the reference's vertical flip
 // (src/Texture.cpp:6-7: stbi_set_flip_vertically_on_load(1), 3 channels forced), and the PNG
 // writer behind out_%03d.png (src/RayTracer.cpp:263-269: 3 channels, stride 3*width).
 // Self-contained: no image library is linked.
@@ -266,57 +266,86 @@ bool load_png(const std::vector<uint8_t>& f, Image& img) {
 		else if (!std::memcmp(type, "IEND", 4)) break;
 		pos += 12 + len;
 	}
-	if (!w || !h || depth != 8 || interlace) return false;
-	int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+	if (!w || !h || interlace > 1 || (uint64_t)w * h > (1ull << 28)) return false;
+	const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
 	if (!ch) return false;
+	if (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16) return false;
+	if (depth < 8 && ctype != 0 && ctype != 3) return false;
+	if (depth == 16 && ctype == 3) return false;
 	std::vector<uint8_t> raw;
-	raw.reserve((size_t)h * ((size_t)w * ch + 1));
 	if (!inflate_zlib(idat.data(), idat.size(), raw)) return false;
-	const size_t stride = (size_t)w * ch;
-	if (raw.size() < (size_t)h * (stride + 1)) return false;
-	std::vector<uint8_t> cur(stride), prev(stride, 0);
 	img.w = (int)w;
 	img.h = (int)h;
 	img.rgb.assign((size_t)w * h * 3, 0);
-	for (uint32_t y = 0; y < h; ++y) {
-		const uint8_t* row = &raw[y * (stride + 1)];
-		int ft = row[0];
-		for (size_t i = 0; i < stride; ++i) {
-			int a = i >= (size_t)ch ? cur[i - ch] : 0, b = prev[i], c = i >= (size_t)ch ? prev[i - ch] : 0;
-			int x = row[1 + i], v;
-			switch (ft) {
-			case 0: v = x; break;
-			case 1: v = x + a; break;
-			case 2: v = x + b; break;
-			case 3: v = x + ((a + b) >> 1); break;
-			case 4: {
-				int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
-				v = x + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c));
-				break;
+	// sample -> byte: 16-bit samples keep their high byte, grey samples below 8 bits are spread over 0..255,
+	// palette indices stay as they are (what stb_image does for an 8-bit load)
+	const int greyScale = (ctype == 0 && depth < 8) ? (depth == 1 ? 255 : depth == 2 ? 85 : 17) : 1;
+	auto put = [&](uint32_t x, uint32_t y, const uint8_t* s8) {
+		uint8_t* dst = &img.rgb[((size_t)y * w + x) * 3];
+		if (ctype == 3) {
+			const size_t k = (size_t)s8[0] * 3;
+			if (k + 2 < plte.size()) {
+				dst[0] = plte[k];
+				dst[1] = plte[k + 1];
+				dst[2] = plte[k + 2];
 			}
-			default: return false;
-			}
-			cur[i] = (uint8_t)v;
 		}
-		uint8_t* dst = &img.rgb[(size_t)y * w * 3];
-		for (uint32_t x = 0; x < w; ++x) {
-			const uint8_t* s = &cur[(size_t)x * ch];
-			if (ctype == 3) {
-				size_t k = (size_t)s[0] * 3;
-				if (k + 2 < plte.size()) {
-					dst[3 * x] = plte[k];
-					dst[3 * x + 1] = plte[k + 1];
-					dst[3 * x + 2] = plte[k + 2];
+		else if (ch <= 2) dst[0] = dst[1] = dst[2] = s8[0];
+		else {
+			dst[0] = s8[0];
+			dst[1] = s8[1];
+			dst[2] = s8[2];
+		}
+	};
+	// the whole image, or the seven Adam7 passes: (x0, y0, dx, dy)
+	static const int adam7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+	size_t at = 0;
+	const size_t bpp = (size_t)std::max(1, ch * depth / 8);  // filter distance in bytes
+	for (int pass = 0; pass < (interlace ? 7 : 1); ++pass) {
+		const int x0 = interlace ? adam7[pass][0] : 0, y0 = interlace ? adam7[pass][1] : 0;
+		const int dx = interlace ? adam7[pass][2] : 1, dy = interlace ? adam7[pass][3] : 1;
+		if ((uint32_t)x0 >= w || (uint32_t)y0 >= h) continue;
+		const uint32_t pw = (w - x0 + dx - 1) / dx, ph = (h - y0 + dy - 1) / dy;
+		const size_t rowBytes = ((size_t)pw * ch * depth + 7) / 8;
+		if (raw.size() < at + (size_t)ph * (rowBytes + 1)) return false;
+		std::vector<uint8_t> cur(rowBytes), prev(rowBytes, 0);
+		for (uint32_t py = 0; py < ph; ++py) {
+			const uint8_t* row = &raw[at];
+			at += rowBytes + 1;
+			const int ft = row[0];
+			for (size_t i = 0; i < rowBytes; ++i) {
+				const int a = i >= bpp ? cur[i - bpp] : 0, b2 = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+				const int x = row[1 + i];
+				int v;
+				switch (ft) {
+				case 0: v = x; break;
+				case 1: v = x + a; break;
+				case 2: v = x + b2; break;
+				case 3: v = x + ((a + b2) >> 1); break;
+				case 4: {
+					const int pr = a + b2 - c, pa = std::abs(pr - a), pb = std::abs(pr - b2), pc = std::abs(pr - c);
+					v = x + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b2 : c));
+					break;
 				}
+				default: return false;
+				}
+				cur[i] = (uint8_t)v;
 			}
-			else if (ch <= 2) dst[3 * x] = dst[3 * x + 1] = dst[3 * x + 2] = s[0];
-			else {
-				dst[3 * x] = s[0];
-				dst[3 * x + 1] = s[1];
-				dst[3 * x + 2] = s[2];
+			for (uint32_t px = 0; px < pw; ++px) {
+				uint8_t s8[4] = {0, 0, 0, 0};
+				if (depth == 8)
+					for (int k = 0; k < ch; ++k) s8[k] = cur[(size_t)px * ch + k];
+				else if (depth == 16)
+					for (int k = 0; k < ch; ++k) s8[k] = cur[((size_t)px * ch + k) * 2];
+				else {
+					const size_t bit = (size_t)px * depth;
+					const int v = (cur[bit >> 3] >> (8 - depth - (int)(bit & 7))) & ((1 << depth) - 1);
+					s8[0] = (uint8_t)(v * greyScale);
+				}
+				put((uint32_t)x0 + px * dx, (uint32_t)y0 + py * dy, s8);
 			}
+			prev.swap(cur);
 		}
-		prev.swap(cur);
 	}
 	return true;
 }
@@ -440,7 +469,7 @@ bool load_tga(const std::vector<uint8_t>& f, Image& img) {
 bool load_texture_file(const std::string& path, Image& img) {
 	std::vector<uint8_t> f;
 	if (!read_file(path, f)) return false;
-	bool ok = load_png(f, img) || load_pnm(f, img) || load_bmp(f, img) || load_tga(f, img);
+	bool ok = load_jpeg(f, img) || load_png(f, img) || load_pnm(f, img) || load_bmp(f, img) || load_tga(f, img);
 	if (!ok) return false;
 	const size_t stride = (size_t)img.w * 3;
 	std::vector<uint8_t> tmp(stride);

@@ -123,3 +123,23 @@ def test_tonemap_table_is_the_host_tonemap(native_libs):
     special = np.zeros((3, 4), np.float32)
     special[:, 0] = [-1.0, -0.0, np.nan]
     assert api.tonemap(special, 1)[:, 0].tolist() == [neg, neg, nan]
+
+
+def test_texture_loaders_match_reference_goldens(native_libs, tmp_path):
+    """tests/golden/images.npz holds image files and what the reference's stb_image decodes from them (three
+    channels, bottom row first, src/Texture.cpp:4-8): JPEG baseline/progressive/subsampled/grey/CMYK, PNG in all
+    bit depths incl. 16-bit, palette and Adam7, BMP, TGA (raw and RLE), PPM/PGM."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "images.npz"))
+    names = [str(n) for n in g["names"]]
+    assert len(names) >= 30 and any(n.endswith(".jpg") for n in names)
+    for k, name in enumerate(names):
+        path = str(tmp_path / name)
+        with open(path, "wb") as f:
+            f.write(g["file_%d" % k].tobytes())
+        got = api.load_texture(path)
+        want = g["pixels_%d" % k]
+        assert got.shape == want.shape and np.array_equal(got, want), name
+    with open(str(tmp_path / "broken.jpg"), "wb") as f:
+        f.write(g["file_0"].tobytes()[:200])
+    with pytest.raises(api.RtxError):
+        api.load_texture(str(tmp_path / "broken.jpg"))

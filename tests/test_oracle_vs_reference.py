@@ -85,3 +85,24 @@ def test_render_rows_sequential_generators():
     acc_o = np.zeros_like(acc_r) + temp * np.float32(0.25)
     assert_bits_equal(acc_o[..., :3], acc_r[..., :3], "accumulator")
     assert np.array_equal(O.tonemap(acc_o, 1).reshape(sc.height, sc.width, 3), out_r)
+
+
+def test_texture_files_decode_like_the_reference(tmp_path):
+    """Texture::Texture(path) (src/Texture.cpp:4-8, the reference's vendored stb_image, three channels, flipped)
+    against the loaders of rtx_image.cpp / rtx_jpeg.cpp: JPEG baseline and progressive in every subsampling, with
+    restart markers, grey and CMYK; PNG in every bit depth, with palette, alpha, 16 bits and Adam7; BMP, TGA, PNM."""
+    import image_cases
+    from raytracer_amd import api
+    R = binding.Reference()
+    rng = np.random.default_rng(7)
+    n = 0
+    for name, data in list(image_cases.jpeg_cases(rng)) + list(image_cases.lossless_cases(rng)):
+        path = str(tmp_path / name)
+        with open(path, "wb") as f:
+            f.write(data)
+        want = R.texture_pixels(path)
+        assert want is not None, name
+        got = api.load_texture(path)
+        assert got.shape == want.shape and np.array_equal(got, want), name
+        n += 1
+    assert n > 120
