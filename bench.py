@@ -52,7 +52,7 @@ def cpu_baseline(sc, nodes, seconds_target=15.0):
         acc = np.zeros((sc.height, sc.width, 4), np.float32)
         return o.render_rows(1, acc, row0=r0, row1=r0 + rows, nthreads=cores), r0
 
-    probe_rows = max(1, cores // 4)
+    probe_rows = cores  # one row per thread, so that the probe sees the parallel rate
     t_probe, _ = timed(obj, probe_rows)
     rows = int(min(sc.height, max(cores // 2, probe_rows * seconds_target / max(t_probe, 1e-3))))
     port.reset_counts()
@@ -225,6 +225,8 @@ def main():
                                "box_tests_per_ray": round(n_node, 2), "triangle_tests_per_ray": round(n_tri, 3),
                                "bytes_per_ray": round(bytes_per_ray, 1),
                                "avg_launch_ms": round(trace_ms_sum / max(counters["launches"] * world, 1), 4),
+                               "traffic_GBps": (round(measured_traffic() / (trace_ms_sum / max(counters["launches"] * world, 1) * 1e-3) / 1e9, 1)
+                                                if measured_traffic() and trace_ms_sum > 0 else None),
                                "note": "the records are re-read from L2/Infinity Cache (tree + triangles = 25 MB), so algorithmic "
                                        "bytes/s can approach the HBM figure without HBM traffic; the kernel's measured limiter is "
                                        "vector-ALU issue (SQ_ACTIVE_INST_VALU ~ 98 % of SIMD cycles), see profiles/"}
