@@ -651,6 +651,7 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 			s->stats.rays += n - hc[1];
 			s->stats.shaded_hits += hc[2];
 			s->stats.texture_fetches += hc[3];
+			s->stats.rays_set_aside += s->hCounts[(size_t)lv * CNT_STRIDE + UNSAFE_SLOT];
 			n = hc[0];
 		}
 	}

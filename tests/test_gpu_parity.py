@@ -258,6 +258,43 @@ def test_external_accumulator_and_resume(libs):
     assert_bits_equal(want, rt.accum(), "resume")
 
 
+def test_trees_the_wide_kernel_cannot_use_and_short_stacks(libs, monkeypatch):
+    """(a) A tree whose leaf boxes are not the triangles' own bounds breaks the premise of the wide traversal:
+    every ray must then go through the binary-tree kernel and still match the restatement walking the same
+    nodes.  (b) With a 16-entry stack some rays overflow in the wide kernel and start over in the binary-tree
+    kernel; the image must not change."""
+    sc = scenes.mixed_scene(seed=12, width=96, height=64, detail=0.7)
+    nodes = api.build_bvh(sc.tris)
+    fat = nodes.copy()
+    fat["bmin"][:, :3] -= np.float32(0.25)
+    fat["bmax"][:, :3] += np.float32(0.25)
+    O = binding.Oracle()
+    load_into(O, sc, build=False)
+    O.set_nodes(fat)
+    rt = api.RayTracer(0)
+    rt.load_scene(sc, fat)
+    ids_o, tab_o = O.primary_hits()
+    for mode in (0, 1):
+        ids_g, tab_g = rt.primary_hits(mode)
+        assert np.array_equal(ids_o, ids_g)
+        assert_bits_equal(tab_o[ids_o >= 0], tab_g[ids_o >= 0], "fat tree, mode %d" % mode)
+    # (b)
+    big = scenes.atrium_scene(width=320, height=200, max_depth=4)
+    bn = api.build_bvh(big.tris)
+    ref = api.RayTracer(0)
+    ref.load_scene(big, bn)
+    ref.reset()
+    ref.render(1, 1)
+    monkeypatch.setenv("RTX_WIDE_STACK", "16")
+    short = api.RayTracer(0)
+    monkeypatch.delenv("RTX_WIDE_STACK")
+    short.load_scene(big, bn)
+    short.reset()
+    short.render(1, 1)
+    assert_bits_equal(ref.accum(), short.accum(), "16-entry stack")
+    assert short.stats()["rays_set_aside"] >= ref.stats()["rays_set_aside"]
+
+
 def test_queue_history_overflow_is_rendered_again(libs):
     """Queues are sized from the ray populations of earlier frames.  History taken from one tile of sky makes
     the queues of the full image far too small: the device notices, stores nothing of such a batch, and the
