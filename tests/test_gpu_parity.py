@@ -240,6 +240,30 @@ def test_atrium_tiles_arena_and_determinism(libs):
     assert_bits_equal(acc_o[96:104, :, :3], full[96:104, :, :3], "rows 96..103 vs CPU")
 
 
+def test_atrium_full_size_rows_equal_restatement(libs):
+    """The benchmark workload itself (atrium, 1920x1080, depth 4, two frames): three rows of the accumulator
+    against the CPU restatement, the frame's ray count against the per-level counts, and the device tone map of
+    the whole frame against the host's."""
+    sc = scenes.atrium_scene(width=1920, height=1080, max_depth=4)
+    nodes = api.build_bvh(sc.tris)
+    rt = api.RayTracer(0)
+    rt.load_scene(sc, nodes)
+    rt.reset()
+    rt.render(1, 2)
+    st = rt.stats()
+    assert st["rays"] == sum(st["rays_per_level"]) and st["rays_per_level"][0] == 2 * 1920 * 1080 * 4
+    assert st["queue_retries"] == 0
+    full = rt.accum()
+    O = binding.Oracle()
+    load_into(O, sc, build=False)
+    O.set_nodes(nodes)
+    acc_o = np.zeros((sc.height, sc.width, 4), np.float32)
+    for f in (1, 2):
+        O.render_rows(f, acc_o, row0=539, row1=542, nthreads=16)
+    assert_bits_equal(acc_o[539:542, :, :3], full[539:542, :, :3], "rows 539..541 vs CPU")
+    assert np.array_equal(rt.tonemap_read(2).reshape(-1, 3), api.tonemap(full, 2))
+
+
 def test_external_accumulator_and_resume(libs):
     import torch
     sc = scenes.mixed_scene(seed=2, width=64, height=40)
