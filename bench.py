@@ -128,7 +128,7 @@ def main():
     batch = max(1, sharder.n_tiles // (world * 8))
 
     counters = {"rays": 0, "trace_ms": 0.0, "shade_ms": 0.0, "launches": 0, "node_tests": 0, "tri_tests": 0,
-                "shaded": 0, "fetches": 0}
+                "shaded": 0, "fetches": 0, "untraced": 0}
 
     def take_stats():
         st = rt.stats()
@@ -138,6 +138,7 @@ def main():
         counters["launches"] += st["trace_launches"]
         counters["shaded"] += st["shaded_hits"]
         counters["fetches"] += st["texture_fetches"]
+        counters["untraced"] += st["rays_untraced"]
 
     def step(frame):
         if args.balance == "static":
@@ -212,12 +213,16 @@ def main():
                        "sharding": "tile-interleave x%d, %s" % (world, "gather to rank 0 per step" if args.balance == "static" else "dynamic batches + reduce per step")},
             "samples_per_s": round(samples / dt, 1),
             "rays_per_step": round(rays_total / args.steps),
+            # rays of the last level that are worth zero hit or miss (counted above: the reference traces them);
+            # this rank's share
+            "rays_untraced_per_step": round(counters["untraced"] / args.steps),
             "gpu_kernel_ms_per_step": {"trace": round(trace_ms_sum / args.steps / world, 3), "shade_gather_accumulate": round(shade_ms_sum / args.steps / world, 3)},
         }
         if n_node is not None:
             # algorithmic bytes the traversal kernel must move per ray: one 64-B record per node of the 4-wide
             # tree it visits, one 64-B record per triangle whose quantised box it enters, 32 B ray in, 16 B hit out
-            bytes_per_ray = 64.0 * n_wide + 64.0 * n_leaf + 48.0
+            # (a ray that is not traversed has only its direction read: 16 B less)
+            bytes_per_ray = 64.0 * n_wide + 64.0 * n_leaf + 48.0 - 16.0 * counters["untraced"] * world / max(rays_total, 1.0)
             achieved = bytes_per_ray * rays_total / (trace_ms_sum / world * 1e-3) / 1e9 if trace_ms_sum > 0 else 0.0
             out["roofline"] = {"bound": "hbm", "kernel": "k_trace_wide", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),

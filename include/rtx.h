@@ -59,6 +59,7 @@ typedef struct rtx_stats {
 	uint64_t leaf_fetches;    /* 64-byte triangle records fetched by the wide traversal (instrumented runs)   */
 	uint64_t queue_retries;   /* pixel batches rendered again because a queue sized from earlier frames overflowed */
 	uint64_t rays_set_aside;  /* rays the wide traversal handed to the binary-tree kernel (rtx_render_frames only)  */
+	uint64_t rays_untraced;   /* last-level rays (counted in rays) whose value is zero hit or miss: not traversed   */
 } rtx_stats;
 
 /* ------------------------------------------------------------------ device side (librtx_hip.so) */

@@ -87,10 +87,13 @@ __device__ __forceinline__ float3 tex_fetch(const DevScene& sc, int id, float u,
 	return make_float3(sc.gammaT[c[0]], sc.gammaT[c[1]], sc.gammaT[c[2]]);
 }
 
-// Skybox::sampleBackground (src/Skybox.cpp:32-84).
-__device__ float3 sky_fetch(const DevScene& sc, float dx, float dy, float dz) {
+// Face selection of Skybox::sampleBackground (src/Skybox.cpp:32-84): the first of front, back, left, right, top,
+// bottom whose divisor is not negative and whose (u, v) lies in [0,1]^2; -1 when none does (the reference then
+// returns zero; that is the case for every direction in the pyramid around -y, since the bottom face's v can
+// never pass).
+__device__ __forceinline__ int sky_face(float dx, float dy, float dz, float& u, float& v) {
 	for (int i = 0; i < 6; ++i) {
-		float divisor, u, v;
+		float divisor;
 		float px, py, pz;
 		switch (i) {
 		case 0:
@@ -131,10 +134,29 @@ __device__ float3 sky_fetch(const DevScene& sc, float dx, float dy, float dz) {
 			break;
 		}
 		if (divisor < 0.0f || u < 0.0f || v < 0.0f || u > 1.0f || v > 1.0f) continue;
-		float3 c = tex_fetch(sc, sc.skyTex[i], u, v);
-		return make_float3(c.x * sc.skyBrightness, c.y * sc.skyBrightness, c.z * sc.skyBrightness);
+		return i;
 	}
-	return make_float3(0.0f, 0.0f, 0.0f);
+	return -1;
+}
+
+// Skybox::sampleBackground (src/Skybox.cpp:32-84).
+__device__ float3 sky_fetch(const DevScene& sc, float dx, float dy, float dz) {
+	float u, v;
+	const int face = sky_face(dx, dy, dz, u, v);
+	if (face < 0) return make_float3(0.0f, 0.0f, 0.0f);
+	float3 c = tex_fetch(sc, sc.skyTex[face], u, v);
+	return make_float3(c.x * sc.skyBrightness, c.y * sc.skyBrightness, c.z * sc.skyBrightness);
+}
+
+// What a ray of the last recursion level is worth is known without tracing it when a miss would return zero:
+// a hit returns zero there anyway (src/RayTracer.cpp:170).  True when the sky has no face for the direction,
+// or when there is no sky and the background is black.
+__device__ __forceinline__ bool miss_is_zero(const DevScene& sc, float dx, float dy, float dz) {
+	if (sc.hasSky) {
+		float u, v;
+		return sky_face(dx, dy, dz, u, v) < 0;
+	}
+	return sc.bg.x == 0.0f && sc.bg.y == 0.0f && sc.bg.z == 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------------

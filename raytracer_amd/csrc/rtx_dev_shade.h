@@ -67,6 +67,7 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 	for (long long base = (long long)blockIdx.x * SHADE_THREADS; base < n; base += (long long)gridDim.x * SHADE_THREADS) {
 		const int j = (int)base + (int)threadIdx.x;
 		const int S = sc.nSpec, Dn = sc.nDiff;
+		const bool lastNext = level + 1 == sc.maxDepth;  // the children are rays of the last level
 		int kind = KIND_LEAF;
 		int flags = 0;
 		int nchild = 0;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 				scatter_offset(sc, key, 0, (uint32_t)i, ox, oy, oz);
 				float cx = rx + ox * rough, cy = ry + oy * rough, cz = rz + oz * rough;
 				nRayO[childBase + i] = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)i)));
-				nRayD[childBase + i] = make_float4(cx, cy, cz, 0.0f);
+				nRayD[childBase + i] = make_float4(cx, cy, cz, (lastNext && miss_is_zero(sc, cx, cy, cz)) ? 2.0f : 0.0f);
 			}
 			if (kind == KIND_DIEL) {
 				// Triangle::diffuse (src/Triangle.cpp:95-119)
@@ -226,7 +227,8 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 					float ox, oy, oz;
 					scatter_offset(sc, key, 1, (uint32_t)i, ox, oy, oz);
 					nRayO[childBase + S + i] = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)(S + i))));
-					nRayD[childBase + S + i] = make_float4(tx + ox, ty + oy, tz + oz, 0.0f);
+					const float ex = tx + ox, ey = ty + oy, ez = tz + oz;
+					nRayD[childBase + S + i] = make_float4(ex, ey, ez, (lastNext && miss_is_zero(sc, ex, ey, ez)) ? 2.0f : 0.0f);
 				}
 			}
 			else if (kind == KIND_TRANSP) {
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 					float reflectProportion = r0 + (1.0f - r0) * pow5;
 					scalar = 1.0f - reflectProportion;
 					nRayO[childBase + S] = ro;
-					nRayD[childBase + S] = make_float4(ex, ey, ez, 0.0f);
+					nRayD[childBase + S] = make_float4(ex, ey, ez, (lastNext && miss_is_zero(sc, ex, ey, ez)) ? 2.0f : 0.0f);
 				}
 			}
 		}
@@ -276,11 +278,12 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 __global__ __launch_bounds__(256) void k_shade_last(DevScene sc, const float4* __restrict__ rayD, const float4* __restrict__ hits,
 													int n, float4* __restrict__ A, unsigned* __restrict__ cnt, const unsigned* __restrict__ nDev) {
 	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
-	unsigned dead = 0, fetches = 0;
+	unsigned dead = 0, fetches = 0, untraced = 0;
 	for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
 		const int rank = __float_as_int(hits[j].x);
 		float3 val = make_float3(0.0f, 0.0f, 0.0f);
 		if (rank == -2) dead++;
+		else if (rank == -3) untraced++;
 		else if (rank == -1) {
 			if (sc.hasSky) {
 				const float4 D = rayD[j];
@@ -295,10 +298,12 @@ __global__ __launch_bounds__(256) void k_shade_last(DevScene sc, const float4* _
 	for (int off = 32; off > 0; off >>= 1) {
 		dead += __shfl_down(dead, off, 64);
 		fetches += __shfl_down(fetches, off, 64);
+		untraced += __shfl_down(untraced, off, 64);
 	}
 	if ((threadIdx.x & 63) == 0) {
 		if (dead) atomicAdd(&cnt[1], dead);
 		if (fetches) atomicAdd(&cnt[3], fetches);
+		if (untraced) atomicAdd(&cnt[2], untraced);  // the slot of the shaded hits, of which this level has none
 	}
 }
 

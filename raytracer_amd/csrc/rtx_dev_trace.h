@@ -97,7 +97,8 @@ __device__ __forceinline__ bool box_test(const RaySlab& r, float4 bmin, float4 b
 	return hit;
 }
 
-// hits[j] = (rank or -1 / -2 for a dead slot, t, alpha, beta), all as raw bits of a float4.
+// hits[j] = (rank, or -1 miss / -2 dead slot / -3 zero-valued ray that was not traced; t; alpha; beta), all as raw
+// bits of a float4.
 // ANYHIT: only "some candidate is accepted" is needed (rays at the last recursion depth,
 // src/RayTracer.cpp:154-171); x = 0 then stands for "hit".
 // EXHAUSTIVE: no culling, i.e. the candidate set of BVH::hit itself.
@@ -122,6 +123,10 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 	if (nDev) n = (int)min(*nDev, (unsigned)n);
 	// with a list: the rays to trace are list[0 .. *listCount), the ones the wide traversal set aside
 	if (list) n = (int)*listCount;
+	// A short queue is cut into smaller chunks, so that every wave of the grid has about three to take: with
+	// chunks of the full size a queue of a million rays would occupy two waves in three and the launch would
+	// last as long as one wave needs for its whole chunk.
+	chunk = min(chunk, max(64, (int)((unsigned)n / (gridDim.x * (TRACE_THREADS / 64) * 3u) + 63u) & ~63));
 	__shared__ int stk[STACK][TRACE_THREADS];
 	const int tid = threadIdx.x;
 	const unsigned lane = (unsigned)tid & 63u;
@@ -183,7 +188,9 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 					float4 O = rayO[j];
 					float4 D = rayD[j];
 					if (D.w != 0.0f) {
-						hits[j] = make_float4(__int_as_float(-2), FLT_MAX, 0.0f, 0.0f);
+						// not to be traced: 1 = no ray at all (refraction under total internal reflection),
+						// 2 = a ray of the last level whose value is zero whether it hits or not
+						hits[j] = make_float4(__int_as_float(D.w == 2.0f ? -3 : -2), FLT_MAX, 0.0f, 0.0f);
 					}
 					else {
 						r.ox = O.x; r.oy = O.y; r.oz = O.z;
@@ -339,6 +346,10 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 															   unsigned* __restrict__ unsafeCount, int refill, int chunk,
 															   int triBatch, const unsigned* __restrict__ nDev) {
 	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
+	// A short queue is cut into smaller chunks, so that every wave of the grid has about three to take: with
+	// chunks of the full size a queue of a million rays would occupy two waves in three and the launch would
+	// last as long as one wave needs for its whole chunk.
+	chunk = min(chunk, max(64, (int)((unsigned)n / (gridDim.x * (TRACE_THREADS / 64) * 3u) + 63u) & ~63));
 	__shared__ int stk[STACK][TRACE_THREADS];
 	const int tid = threadIdx.x;
 	const unsigned lane = (unsigned)tid & 63u;
@@ -393,7 +404,9 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 					float4 O = rayO[j];
 					float4 D = rayD[j];
 					if (D.w != 0.0f) {
-						hits[j] = make_float4(__int_as_float(-2), FLT_MAX, 0.0f, 0.0f);
+						// not to be traced: 1 = no ray at all (refraction under total internal reflection),
+						// 2 = a ray of the last level whose value is zero whether it hits or not
+						hits[j] = make_float4(__int_as_float(D.w == 2.0f ? -3 : -2), FLT_MAX, 0.0f, 0.0f);
 					}
 					else {
 						r.ox = O.x; r.oy = O.y; r.oz = O.z;

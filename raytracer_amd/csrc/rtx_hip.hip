@@ -132,7 +132,7 @@ struct EventPair {
 struct rtx_scene {
 	int device = 0;
 	int numCUs = 256;
-	int traceRefill = TRACE_REFILL, traceChunk = TRACE_CHUNK, traceBlocksPerCU = 8, traceTriBatch = 24;  // tunables (RTX_TRACE_* env)
+	int traceRefill = TRACE_REFILL, traceChunk = TRACE_CHUNK, traceBlocksPerCU = 6, traceTriBatch = 24;  // tunables (RTX_TRACE_* env)
 	hipStream_t stream = nullptr;
 	hipStream_t ownStream = nullptr;
 	// parameters
@@ -649,7 +649,8 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 			const unsigned* hc = s->hCounts + (size_t)(lv + 1) * CNT_STRIDE;
 			s->stats.rays_per_level[lv] += n - hc[1];
 			s->stats.rays += n - hc[1];
-			s->stats.shaded_hits += hc[2];
+			if (lv == s->maxDepth) s->stats.rays_untraced += hc[2];  // the last level shades nothing
+			else s->stats.shaded_hits += hc[2];
 			s->stats.texture_fetches += hc[3];
 			s->stats.rays_set_aside += s->hCounts[(size_t)lv * CNT_STRIDE + UNSAFE_SLOT];
 			n = hc[0];

@@ -91,6 +91,35 @@ def test_radiance_and_accumulator_bit_exact(libs, seed, w, h, depth, nd, ns, sky
     assert np.array_equal(api.tonemap(rt.accum(), 3), O.tonemap(acc_o, 3))
 
 
+@pytest.mark.parametrize("sky,black", [(True, False), (False, True), (False, False)])
+def test_last_level_rays_whose_value_is_known_are_not_traced(libs, sky, black):
+    """A ray of the last level returns zero on a hit (src/RayTracer.cpp:170); where a miss is zero too (no sky
+    face for the direction, src/Skybox.cpp:32-84, or no sky over a black background) the product skips the
+    traversal.  The image and the ray count must not change, and the skipped rays are reported."""
+    w, h, depth = 80, 48, 2
+    sc = scenes.mixed_scene(seed=9, width=w, height=h, max_depth=depth, n_diff=2, n_spec=1, with_sky=sky)
+    if black:
+        sc.bg = (0.0, 0.0, 0.0)
+    O = load_into(binding.Oracle(), sc)
+    rt = gpu_scene(sc)
+    assert_bits_equal(O.sample_radiance(1, 0, 0, w, h)[..., :3], rt.sample_radiance(1)[..., :3], "per-sample radiance")
+    acc_o = np.zeros((h, w, 4), np.float32)
+    O.reset_counts()
+    O.render_rows(1, acc_o, nthreads=8)
+    rt.reset()
+    rt.render(1, 1)
+    assert_bits_equal(acc_o[..., :3], rt.accum()[..., :3], "accumulator")
+    st = rt.stats()
+    assert st["rays"] == O.ray_count()
+    last = st["rays_per_level"][depth]
+    if black:
+        assert st["rays_untraced"] == last > 0
+    elif sky:
+        assert 0 < st["rays_untraced"] < last      # the directions around -y have no sky face
+    else:
+        assert st["rays_untraced"] == 0
+
+
 def test_secondary_like_rays_and_degenerate_rays(libs):
     sc = scenes.mixed_scene(seed=4, width=16, height=16, detail=0.8)
     O = load_into(binding.Oracle(), sc)
