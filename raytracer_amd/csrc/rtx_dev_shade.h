@@ -272,27 +272,36 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 	}
 }
 
+// What a ray of the last level returns, from its any-hit answer (src/RayTracer.cpp:148-152,170): a hit is worth
+// zero, a miss the sky or the background.
+__device__ __forceinline__ float3 last_level_value(const DevScene& sc, int code, const float4* __restrict__ rayD, unsigned slot,
+												   unsigned& dead, unsigned& fetches, unsigned& untraced) {
+	float3 val = make_float3(0.0f, 0.0f, 0.0f);
+	if (code == -2) dead++;
+	else if (code == -3) untraced++;
+	else if (code == -1) {
+		if (sc.hasSky) {
+			const float4 D = rayD[slot];
+			val = sky_fetch(sc, D.x, D.y, D.z);
+			fetches++;
+		}
+		else
+			val = make_float3(sc.bg.x, sc.bg.y, sc.bg.z);
+	}
+	return val;
+}
+
 // The rays of the last recursion level end their paths whatever they hit: a hit returns zero
 // (src/RayTracer.cpp:170), a miss the sky or the background (:148-152).  Only A is written (B and C of the
-// last level are never read).  Blocks stride over the queue so that each adds its counts once.
+// last level are never read).  Blocks stride over the queue so that each adds its counts once.  Launched when
+// the last level is the first (max_recursion_depth 0); otherwise k_gather<true> does this on the way.
 __global__ __launch_bounds__(256) void k_shade_last(DevScene sc, const float4* __restrict__ rayD, const float4* __restrict__ hits,
 													int n, float4* __restrict__ A, unsigned* __restrict__ cnt, const unsigned* __restrict__ nDev) {
 	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
+	const int* __restrict__ codes = reinterpret_cast<const int*>(hits);  // any-hit answers: one int per ray
 	unsigned dead = 0, fetches = 0, untraced = 0;
 	for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
-		const int rank = __float_as_int(hits[j].x);
-		float3 val = make_float3(0.0f, 0.0f, 0.0f);
-		if (rank == -2) dead++;
-		else if (rank == -3) untraced++;
-		else if (rank == -1) {
-			if (sc.hasSky) {
-				const float4 D = rayD[j];
-				val = sky_fetch(sc, D.x, D.y, D.z);
-				fetches++;
-			}
-			else
-				val = make_float3(sc.bg.x, sc.bg.y, sc.bg.z);
-		}
+		const float3 val = last_level_value(sc, codes[j], rayD, (unsigned)j, dead, fetches, untraced);
 		A[j] = make_float4(val.x, val.y, val.z, 0.0f);
 	}
 	for (int off = 32; off > 0; off >>= 1) {
@@ -310,19 +319,31 @@ __global__ __launch_bounds__(256) void k_shade_last(DevScene sc, const float4* _
 // Combine step of RayTracer::color for the nodes of one level, children read from the next
 // level (src/RayTracer.cpp:177-224).  Sums start from zero and run in child order, scale
 // factors are applied after the sum, exactly as the reference does.
-__global__ __launch_bounds__(256) void k_gather(int S, int Dn, int n, float4* __restrict__ A,
-												const int4* __restrict__ B, const float4* __restrict__ C,
-												const float4* __restrict__ childA, const unsigned* __restrict__ nDev) {
+// LAST: the children are the rays of the last level and their values are worked out here, from the any-hit
+// answers (`codes`) and the rays' directions, instead of being read from childA; cnt is then the counter block
+// the last level's shade kernel would have written (dead slots, untraced rays, texel fetches).
+template <bool LAST>
+__global__ __launch_bounds__(256) void k_gather(DevScene sc, int n, float4* __restrict__ A, const int4* __restrict__ B,
+												const float4* __restrict__ C, const float4* __restrict__ childA,
+												const int* __restrict__ codes, const float4* __restrict__ childD,
+												unsigned* __restrict__ cnt, const unsigned* __restrict__ nDev) {
 	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
+	const int S = sc.nSpec, Dn = sc.nDiff;
+	unsigned dead = 0, fetches = 0, untraced = 0;
 	for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
 		int4 b = B[j];
 		const int kind = b.y & 0xFF;
 		if (kind == KIND_LEAF) continue;
 		const float4 col = A[j];
-		const float4* ch = childA + (unsigned)b.x;
+		const unsigned first = (unsigned)b.x;
 		float sx = 0.0f, sy = 0.0f, sz = 0.0f;
 		for (int i = 0; i < S; ++i) {
-			float4 c = ch[i];
+			float3 c;
+			if (LAST) c = last_level_value(sc, codes[first + i], childD, first + i, dead, fetches, untraced);
+			else {
+				const float4 v = childA[first + i];
+				c = make_float3(v.x, v.y, v.z);
+			}
 			sx = sx + c.x;
 			sy = sy + c.y;
 			sz = sz + c.z;
@@ -339,7 +360,15 @@ __global__ __launch_bounds__(256) void k_gather(int S, int Dn, int n, float4* __
 			sy = sy / fS;
 			sz = sz / fS;
 			const float rp = __int_as_float(b.z);
-			float4 rc = (b.y & FLAG_TIR) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : ch[S];
+			float3 rc = make_float3(0.0f, 0.0f, 0.0f);
+			if (b.y & FLAG_TIR) {
+				if (LAST) dead++;  // the slot of the refracted ray that does not exist
+			}
+			else if (LAST) rc = last_level_value(sc, codes[first + S], childD, first + S, dead, fetches, untraced);
+			else {
+				const float4 v = childA[first + S];
+				rc = make_float3(v.x, v.y, v.z);
+			}
 			const float q = 1.0f - rp;
 			ox = rp * rc.x + q * sx;
 			oy = rp * rc.y + q * sy;
@@ -352,7 +381,12 @@ __global__ __launch_bounds__(256) void k_gather(int S, int Dn, int n, float4* __
 			sz = sz * w;
 			float dx = 0.0f, dy = 0.0f, dz = 0.0f;
 			for (int i = 0; i < Dn; ++i) {
-				float4 c = ch[S + i];
+				float3 c;
+				if (LAST) c = last_level_value(sc, codes[first + S + i], childD, first + S + i, dead, fetches, untraced);
+				else {
+					const float4 v = childA[first + S + i];
+					c = make_float3(v.x, v.y, v.z);
+				}
 				dx = dx + c.x;
 				dy = dy + c.y;
 				dz = dz + c.z;
@@ -373,6 +407,18 @@ __global__ __launch_bounds__(256) void k_gather(int S, int Dn, int n, float4* __
 			}
 		}
 		A[j] = make_float4(ox, oy, oz, 0.0f);
+	}
+	if (LAST) {
+		for (int off = 32; off > 0; off >>= 1) {
+			dead += __shfl_down(dead, off, 64);
+			fetches += __shfl_down(fetches, off, 64);
+			untraced += __shfl_down(untraced, off, 64);
+		}
+		if ((threadIdx.x & 63) == 0) {
+			if (dead) atomicAdd(&cnt[1], dead);
+			if (fetches) atomicAdd(&cnt[3], fetches);
+			if (untraced) atomicAdd(&cnt[2], untraced);
+		}
 	}
 }
 

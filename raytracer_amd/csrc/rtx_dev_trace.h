@@ -100,7 +100,8 @@ __device__ __forceinline__ bool box_test(const RaySlab& r, float4 bmin, float4 b
 // hits[j] = (rank, or -1 miss / -2 dead slot / -3 zero-valued ray that was not traced; t; alpha; beta), all as raw
 // bits of a float4.
 // ANYHIT: only "some candidate is accepted" is needed (rays at the last recursion depth,
-// src/RayTracer.cpp:154-171); x = 0 then stands for "hit".
+// src/RayTracer.cpp:154-171); the answer is then one int per ray, the code alone with 0 for "hit", and the
+// buffer is read as an int array.
 // EXHAUSTIVE: no culling, i.e. the candidate set of BVH::hit itself.
 //
 // Persistent waves: rays of one queue differ in traversal length by orders of magnitude, so a wave
@@ -110,6 +111,12 @@ __device__ __forceinline__ bool box_test(const RaySlab& r, float4 bmin, float4 b
 // Every wave leaves the loop when the queue is exhausted and its lanes have drained.
 constexpr int TRACE_CHUNK = 256;
 constexpr int TRACE_REFILL = 16;
+
+template <bool ANYHIT>
+__device__ __forceinline__ void put_hit(float4* __restrict__ hits, int j, int code, float t, float alpha, float beta) {
+	if (ANYHIT) reinterpret_cast<int*>(hits)[j] = code;
+	else hits[j] = make_float4(__int_as_float(code), t, alpha, beta);
+}
 
 template <int STACK, bool ANYHIT, bool EXHAUSTIVE, bool STATS>
 __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const float4* __restrict__ rayO,
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 					if (D.w != 0.0f) {
 						// not to be traced: 1 = no ray at all (refraction under total internal reflection),
 						// 2 = a ray of the last level whose value is zero whether it hits or not
-						hits[j] = make_float4(__int_as_float(D.w == 2.0f ? -3 : -2), FLT_MAX, 0.0f, 0.0f);
+						put_hit<ANYHIT>(hits, j, D.w == 2.0f ? -3 : -2, FLT_MAX, 0.0f, 0.0f);
 					}
 					else {
 						r.ox = O.x; r.oy = O.y; r.oz = O.z;
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 		}
 		if (busy && cur < 0 && pend0 < 0) {
 			int id = found ? (ANYHIT ? 0 : best.rank) : -1;
-			hits[j] = make_float4(__int_as_float(id), best.t, best.alpha, best.beta);
+			put_hit<ANYHIT>(hits, j, id, best.t, best.alpha, best.beta);
 			busy = false;
 		}
 	}
@@ -357,6 +364,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 	unsigned boxTests = 0, triTests = 0, nodeVisits = 0, leafFetches = 0;
 	unsigned walkIters = 0, leafIters = 0, walkLanes = 0, leafLanes = 0;  // wave-level, kept by lane 0
 	unsigned overflows = 0;
+	unsigned myVisits = 0, maxVisits = 0, over100 = 0, over300 = 0;
 	int cnext = 0, cend = 0;
 	bool more = true, firstChunk = true;
 	int j = -1, cur = -1, sp = 0;
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 					if (D.w != 0.0f) {
 						// not to be traced: 1 = no ray at all (refraction under total internal reflection),
 						// 2 = a ray of the last level whose value is zero whether it hits or not
-						hits[j] = make_float4(__int_as_float(D.w == 2.0f ? -3 : -2), FLT_MAX, 0.0f, 0.0f);
+						put_hit<ANYHIT>(hits, j, D.w == 2.0f ? -3 : -2, FLT_MAX, 0.0f, 0.0f);
 					}
 					else {
 						r.ox = O.x; r.oy = O.y; r.oz = O.z;
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 										  ((aiz <= WIDE_MAX_INV) | (aiz > FLT_MAX));
 						if (zero | !finite) {
 							// no triangle can accept such a ray (see k_trace)
-							hits[j] = make_float4(__int_as_float(-1), FLT_MAX, 0.0f, 0.0f);
+							put_hit<ANYHIT>(hits, j, -1, FLT_MAX, 0.0f, 0.0f);
 						}
 						else if (!safe) {
 							unsafeList[atomicAdd(unsafeCount, 1u)] = j;
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 			if (cur >= 0) {
 				const float4* W = sc.wide + (size_t)cur * 4;
 				float4 w0 = W[0], w1 = W[1], w2 = W[2], w3 = W[3];
-				if (STATS) nodeVisits++;
+				if (STATS) { nodeVisits++; myVisits++; }
 				const float Sx = w0.w * wix, Sy = w3.z * wiy, Sz = w3.w * wiz;
 				const float Ax = (w0.x - r.ox) * wix, Ay = (w0.y - r.oy) * wiy, Az = (w0.z - r.oz) * wiz;
 				const float Anx = Ax - r.mx, Any = Ay - r.my, Anz = Az - r.mz;
@@ -603,11 +611,15 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 		}
 		if (busy && cur < 0 && pend0 < 0 && sp == 0) {
 			int id = found ? (ANYHIT ? 0 : best.rank) : -1;
-			hits[j] = make_float4(__int_as_float(id), best.t, best.alpha, best.beta);
+			put_hit<ANYHIT>(hits, j, id, best.t, best.alpha, best.beta);
 			busy = false;
+			if (STATS) { maxVisits = max(maxVisits, myVisits); over100 += myVisits > 100; over300 += myVisits > 300; myVisits = 0; }
 		}
 	}
 	if (STATS) {
+		atomicMax(&stats[9], (unsigned long long)maxVisits);
+		atomicAdd(&stats[10], (unsigned long long)over100);
+		atomicAdd(&stats[11], (unsigned long long)over300);
 		for (int off = 32; off > 0; off >>= 1) {
 			boxTests += __shfl_down(boxTests, off, 64);
 			triTests += __shfl_down(triTests, off, 64);

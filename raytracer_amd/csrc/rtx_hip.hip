@@ -493,10 +493,12 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 	level_ratios(s, useHistory, levels, ratio);
 	double sumRatio = 0.0, maxRatio = 0.0;
 	for (int lv = 0; lv <= levels; ++lv) {
-		sumRatio += ratio[lv];
+		// the last level keeps no node records unless it is the only one (its values are formed inside the
+		// gather of the level above)
+		if (lv < levels || levels == 0) sumRatio += ratio[lv];
 		maxRatio = std::max(maxRatio, ratio[lv]);
 	}
-	// per sample: A, B, C of every level; two ping-pong ray sets and the set-aside list sized for the widest level
+	// per sample: A, B, C of those levels; two ping-pong ray sets and the set-aside list sized for the widest level
 	const double perSample = (mode == 2) ? (double)(NODE_BYTES + 2 * RAY_BYTES + 4) : sumRatio * NODE_BYTES + maxRatio * (2.0 * RAY_BYTES + 4.0);
 	const double fixedBytes = (double)(MAX_DEPTH + 8) * 4096 + (double)(levels + 1) * 1024.0 * NODE_BYTES + 1024.0 * (2.0 * RAY_BYTES + 4.0) + 65536.0;
 	const long long totalBlocks = gEnd - gBegin;
@@ -585,10 +587,11 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 		float4* C[MAX_DEPTH + 1];
 		for (int lv = 0; lv <= s->maxDepth; ++lv) {
 			const size_t n = cap[lv];
-			A[lv] = (float4*)bump.take(n * 16);
-			B[lv] = (int4*)bump.take(n * 16);
-			C[lv] = (float4*)bump.take(n * 16);
-			if (!A[lv] || !B[lv] || !C[lv]) return fail(RTX_ERR_MEMORY, "work arena exhausted (internal sizing error)");
+			const bool keepsNodes = lv < s->maxDepth || lv == 0;
+			A[lv] = keepsNodes ? (float4*)bump.take(n * 16) : nullptr;
+			B[lv] = keepsNodes ? (int4*)bump.take(n * 16) : nullptr;
+			C[lv] = keepsNodes ? (float4*)bump.take(n * 16) : nullptr;
+			if (keepsNodes && (!A[lv] || !B[lv] || !C[lv])) return fail(RTX_ERR_MEMORY, "work arena exhausted (internal sizing error)");
 			const int cur = lv & 1, nxt = cur ^ 1;
 			const unsigned* nDev = lv ? s->dCounts.p + (size_t)lv * CNT_STRIDE : nullptr;
 			rc = launch_trace(s, d, lv == s->maxDepth, false, rayO[cur], rayD[cur], hit[cur], (int)n,
@@ -597,7 +600,9 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 			unsigned* cnt = s->dCounts.p + (size_t)(lv + 1) * CNT_STRIDE;
 			rc = begin_event(s, 1, ev);
 			if (rc) return rc;
-			if (lv == s->maxDepth)
+			if (lv == s->maxDepth && lv > 0)
+				;  // the gather of the level above reads the any-hit answers itself
+			else if (lv == s->maxDepth)
 				hipLaunchKernelGGL(k_shade_last, dim3((unsigned)std::min<size_t>((n + 255) / 256, (size_t)s->numCUs * 8)), dim3(256), 0, s->stream,
 								   d, rayD[cur], hit[cur], (int)n, A[lv], cnt, nDev);
 			else
@@ -612,8 +617,16 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 		if (rc) return rc;
 		for (int lv = s->maxDepth - 1; lv >= 0; --lv) {
 			const unsigned* nDev = lv ? s->dCounts.p + (size_t)lv * CNT_STRIDE : nullptr;
-			hipLaunchKernelGGL(k_gather, dim3((unsigned)std::min<size_t>((cap[lv] + 255) / 256, (size_t)s->numCUs * 16)), dim3(256), 0, s->stream,
-							   s->nSpec, s->nDiff, (int)cap[lv], A[lv], B[lv], C[lv], A[lv + 1], nDev);
+			const dim3 grid((unsigned)std::min<size_t>((cap[lv] + 255) / 256, (size_t)s->numCUs * 16));
+			if (lv == s->maxDepth - 1) {
+				// the children are the last level: its rays and any-hit answers lie in the buffers of its parity
+				const int last = s->maxDepth & 1;
+				hipLaunchKernelGGL(k_gather<true>, grid, dim3(256), 0, s->stream, d, (int)cap[lv], A[lv], B[lv], C[lv], (const float4*)nullptr,
+								   (const int*)hit[last], (const float4*)rayD[last], s->dCounts.p + (size_t)(s->maxDepth + 1) * CNT_STRIDE, nDev);
+			}
+			else
+				hipLaunchKernelGGL(k_gather<false>, grid, dim3(256), 0, s->stream, d, (int)cap[lv], A[lv], B[lv], C[lv], (const float4*)A[lv + 1],
+								   (const int*)nullptr, (const float4*)nullptr, (unsigned*)nullptr, nDev);
 			HIPCHK(hipGetLastError());
 		}
 		const int npix = b.nSamples / 4;
@@ -673,10 +686,12 @@ int finish_stats(rtx_scene* s) {
 		HIPCHK(hipMemcpy(s->hStats, s->dStats.p, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 		s->stats.node_tests = s->hStats[0];
 		s->stats.tri_tests = s->hStats[1];
-		if (std::getenv("RTX_TRACE_DEBUG"))
+		if (std::getenv("RTX_TRACE_DEBUG")) {
 			std::fprintf(stderr, "[rtx] wide: walk iterations %llu with %.1f lanes, leaf phases %llu with %.1f lanes, %llu stack overflows\n", s->hStats[2],
 						 (double)s->hStats[3] / (double)std::max(1ull, s->hStats[2]), s->hStats[6],
 						 (double)s->hStats[7] / (double)std::max(1ull, s->hStats[6]), s->hStats[8]);
+			std::fprintf(stderr, "[rtx] wide: most node visits of one ray %llu, rays over 100: %llu, over 300: %llu\n", s->hStats[9], s->hStats[10], s->hStats[11]);
+		}
 		s->stats.wide_visits = s->hStats[4];
 		s->stats.leaf_fetches = s->hStats[5];
 	}
