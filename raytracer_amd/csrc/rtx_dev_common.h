@@ -19,8 +19,9 @@ constexpr int SAMPLES_PER_BLOCK = BLK * BLK * 4;  // 64 = one wave
 constexpr int TRACE_THREADS = 256;
 
 enum NodeKind : int { KIND_LEAF = 0, KIND_METAL = 1, KIND_TRANSP = 2, KIND_DIEL = 3 };
-constexpr int FLAG_TEX = 0x100;
-constexpr int FLAG_TIR = 0x200;
+// a node's tag word: kind in bits 0-3, flags in bits 4-5, the texel's three bytes in bits 8-31
+constexpr int FLAG_TEX = 0x10;
+constexpr int FLAG_TIR = 0x20;
 
 constexpr int TRI_EMIT = 1, TRI_METAL = 2, TRI_TRANSP = 4;
 
@@ -85,6 +86,19 @@ __device__ __forceinline__ float3 tex_fetch(const DevScene& sc, int id, float u,
 	int sy = (int)roundf(v * vMax);
 	const uint8_t* c = sc.texels + (size_t)(uint32_t)d.x + ((size_t)sy * (size_t)d.y + (size_t)sx) * 3;
 	return make_float3(sc.gammaT[c[0]], sc.gammaT[c[1]], sc.gammaT[c[2]]);
+}
+
+// The same texel as raw bytes (r | g << 8 | b << 16): whoever needs the colour looks the bytes up in gammaT.
+__device__ __forceinline__ unsigned tex_fetch_rgb(const DevScene& sc, int id, float u, float v) {
+	int4 d = sc.texDesc[id];
+	u = clamp01(u);
+	v = clamp01(v);
+	float uMax = (float)(d.y - 1);
+	float vMax = (float)(d.z - 1);
+	int sx = (int)roundf(u * uMax);
+	int sy = (int)roundf(v * vMax);
+	const uint8_t* c = sc.texels + (size_t)(uint32_t)d.x + ((size_t)sy * (size_t)d.y + (size_t)sx) * 3;
+	return (unsigned)c[0] | ((unsigned)c[1] << 8) | ((unsigned)c[2] << 16);
 }
 
 // Face selection of Skybox::sampleBackground (src/Skybox.cpp:32-84): the first of front, back, left, right, top,

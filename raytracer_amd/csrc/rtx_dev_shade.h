@@ -32,10 +32,10 @@ __global__ __launch_bounds__(256) void k_raygen(DevScene sc, Batch b, uint32_t f
 
 // ------------------------------------------------------------------------------------------------
 // Shade.  One thread per ray of level `level`.  Writes the path-node record of this ray:
-//   A[j]  leaf: its radiance.   interior: triangle colour (replaced by the node's radiance in k_gather)
-//   B[j]  (first child slot, kind | flags, scalar as float bits, -)   scalar = |n.d| (dielectric) or
-//         the refracted proportion (transparent)
-//   C[j]  texel of a textured dielectric
+//   A[j]  leaf: its radiance, 0.   interior: triangle colour, scalar (replaced by the node's radiance in
+//         k_gather); scalar = |n.d| (dielectric) or the refracted proportion (transparent)
+//   B[j]  (first child slot, tag); tag = kind | flags | the texel's three bytes << 8 (textured dielectric; the
+//         gather turns the bytes into the colour with the same table a texture look-up uses)
 // and appends the node's child rays to the next level's queue.  cnt[0] receives the queue
 // length, cnt[1] dead slots (refraction under total internal reflection), cnt[2] shaded hits,
 // cnt[3] texel fetches.
@@ -55,7 +55,7 @@ constexpr int SHADE_THREADS = 1024;  // 16 waves share one queue-tail atomic
 
 __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level, const float4* __restrict__ rayO,
 											   const float4* __restrict__ rayD, const float4* __restrict__ hits, int n,
-											   float4* __restrict__ A, int4* __restrict__ B, float4* __restrict__ C,
+											   float4* __restrict__ A, int2* __restrict__ B,
 											   float4* __restrict__ nRayO, float4* __restrict__ nRayD,
 											   unsigned* __restrict__ cnt, unsigned nextCap, const unsigned* __restrict__ nDev) {
 	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 		int nchild = 0;
 		float3 val = make_float3(0.0f, 0.0f, 0.0f);
 		float scalar = 0.0f;
-		float3 texel = make_float3(0.0f, 0.0f, 0.0f);
+		unsigned texel = 0;  // the three bytes of the texel
 		// state needed after the allocation
 		float hx = 0, hy = 0, hz = 0, nx = 0, ny = 0, nz = 0, dx = 0, dy = 0, dz = 0, rough = 0, ior = 1;
 		uint32_t key = 0;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 							const float4 u01 = sc.triUv[(size_t)rank * 2], u2 = sc.triUv[(size_t)rank * 2 + 1];
 							float u = (alpha * u01.x + beta * u01.z) + g * u2.x;
 							float v = (alpha * u01.y + beta * u01.w) + g * u2.y;
-							texel = tex_fetch(sc, texId, u, v);
+							texel = tex_fetch_rgb(sc, texId, u, v);
 							fetches = 1;
 						}
 					}
@@ -264,9 +264,8 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 			}
 		}
 		if (active) {
-			A[j] = make_float4(val.x, val.y, val.z, 0.0f);
-			B[j] = make_int4((int)childBase, kind | flags, __float_as_int(scalar), 0);
-			if (flags & FLAG_TEX) C[j] = make_float4(texel.x, texel.y, texel.z, 0.0f);
+			A[j] = make_float4(val.x, val.y, val.z, scalar);
+			B[j] = make_int2((int)childBase, kind | flags | (int)(texel << 8));
 		}
 		__syncthreads();  // the LDS words are reused by the next round
 	}
@@ -323,16 +322,16 @@ __global__ __launch_bounds__(256) void k_shade_last(DevScene sc, const float4* _
 // answers (`codes`) and the rays' directions, instead of being read from childA; cnt is then the counter block
 // the last level's shade kernel would have written (dead slots, untraced rays, texel fetches).
 template <bool LAST>
-__global__ __launch_bounds__(256) void k_gather(DevScene sc, int n, float4* __restrict__ A, const int4* __restrict__ B,
-												const float4* __restrict__ C, const float4* __restrict__ childA,
+__global__ __launch_bounds__(256) void k_gather(DevScene sc, int n, float4* __restrict__ A, const int2* __restrict__ B,
+												const float4* __restrict__ childA,
 												const int* __restrict__ codes, const float4* __restrict__ childD,
 												unsigned* __restrict__ cnt, const unsigned* __restrict__ nDev) {
 	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
 	const int S = sc.nSpec, Dn = sc.nDiff;
 	unsigned dead = 0, fetches = 0, untraced = 0;
 	for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
-		int4 b = B[j];
-		const int kind = b.y & 0xFF;
+		const int2 b = B[j];
+		const int kind = b.y & 0xF;
 		if (kind == KIND_LEAF) continue;
 		const float4 col = A[j];
 		const unsigned first = (unsigned)b.x;
@@ -359,7 +358,7 @@ __global__ __launch_bounds__(256) void k_gather(DevScene sc, int n, float4* __re
 			sx = sx / fS;
 			sy = sy / fS;
 			sz = sz / fS;
-			const float rp = __int_as_float(b.z);
+			const float rp = col.w;
 			float3 rc = make_float3(0.0f, 0.0f, 0.0f);
 			if (b.y & FLAG_TIR) {
 				if (LAST) dead++;  // the slot of the refracted ray that does not exist
@@ -395,15 +394,15 @@ __global__ __launch_bounds__(256) void k_gather(DevScene sc, int n, float4* __re
 			dx = (dx * col.x) / fD;
 			dy = (dy * col.y) / fD;
 			dz = (dz * col.z) / fD;
-			const float ad = __int_as_float(b.z);
+			const float ad = col.w;
 			ox = sx + dx * ad;
 			oy = sy + dy * ad;
 			oz = sz + dz * ad;
 			if (b.y & FLAG_TEX) {
-				float4 tx = C[j];
-				ox = ox * tx.x;
-				oy = oy * tx.y;
-				oz = oz * tx.z;
+				const unsigned rgb = (unsigned)b.y >> 8;
+				ox = ox * sc.gammaT[rgb & 0xFFu];
+				oy = oy * sc.gammaT[(rgb >> 8) & 0xFFu];
+				oz = oz * sc.gammaT[rgb >> 16];
 			}
 		}
 		A[j] = make_float4(ox, oy, oz, 0.0f);

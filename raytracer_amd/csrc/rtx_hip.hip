@@ -311,7 +311,7 @@ int ensure_ready(rtx_scene* s, bool needCamera) {
 
 // Queue bytes.  Persistent per path node: A (16) + B (16) + C (16); transient, two ping-pong sets sized
 // for the widest level: origin (16) + direction (16) + hit (16).
-constexpr size_t NODE_BYTES = 48, RAY_BYTES = 48;
+constexpr size_t NODE_BYTES = 24, RAY_BYTES = 48;
 
 struct EventScope {
 	rtx_scene* s;
@@ -583,15 +583,13 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 		// block, written by the shade kernel of the level above), arrays are carved at the level's capacity
 		// and grids are fixed.  The host reads the counters once, after the batch.
 		float4* A[MAX_DEPTH + 1];
-		int4* B[MAX_DEPTH + 1];
-		float4* C[MAX_DEPTH + 1];
+		int2* B[MAX_DEPTH + 1];
 		for (int lv = 0; lv <= s->maxDepth; ++lv) {
 			const size_t n = cap[lv];
 			const bool keepsNodes = lv < s->maxDepth || lv == 0;
 			A[lv] = keepsNodes ? (float4*)bump.take(n * 16) : nullptr;
-			B[lv] = keepsNodes ? (int4*)bump.take(n * 16) : nullptr;
-			C[lv] = keepsNodes ? (float4*)bump.take(n * 16) : nullptr;
-			if (keepsNodes && (!A[lv] || !B[lv] || !C[lv])) return fail(RTX_ERR_MEMORY, "work arena exhausted (internal sizing error)");
+			B[lv] = keepsNodes ? (int2*)bump.take(n * 8) : nullptr;
+			if (keepsNodes && (!A[lv] || !B[lv])) return fail(RTX_ERR_MEMORY, "work arena exhausted (internal sizing error)");
 			const int cur = lv & 1, nxt = cur ^ 1;
 			const unsigned* nDev = lv ? s->dCounts.p + (size_t)lv * CNT_STRIDE : nullptr;
 			rc = launch_trace(s, d, lv == s->maxDepth, false, rayO[cur], rayD[cur], hit[cur], (int)n,
@@ -607,7 +605,7 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 								   d, rayD[cur], hit[cur], (int)n, A[lv], cnt, nDev);
 			else
 				hipLaunchKernelGGL(k_shade, dim3((unsigned)std::min<size_t>((n + SHADE_THREADS - 1) / SHADE_THREADS, (size_t)s->numCUs * 4)), dim3(SHADE_THREADS), 0, s->stream, d, lv,
-								   rayO[cur], rayD[cur], hit[cur], (int)n, A[lv], B[lv], C[lv], rayO[nxt], rayD[nxt], cnt, (unsigned)cap[lv + 1],
+								   rayO[cur], rayD[cur], hit[cur], (int)n, A[lv], B[lv], rayO[nxt], rayD[nxt], cnt, (unsigned)cap[lv + 1],
 								   nDev);
 			HIPCHK(hipGetLastError());
 			rc = end_event(s, ev);
@@ -621,11 +619,11 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 			if (lv == s->maxDepth - 1) {
 				// the children are the last level: its rays and any-hit answers lie in the buffers of its parity
 				const int last = s->maxDepth & 1;
-				hipLaunchKernelGGL(k_gather<true>, grid, dim3(256), 0, s->stream, d, (int)cap[lv], A[lv], B[lv], C[lv], (const float4*)nullptr,
+				hipLaunchKernelGGL(k_gather<true>, grid, dim3(256), 0, s->stream, d, (int)cap[lv], A[lv], B[lv], (const float4*)nullptr,
 								   (const int*)hit[last], (const float4*)rayD[last], s->dCounts.p + (size_t)(s->maxDepth + 1) * CNT_STRIDE, nDev);
 			}
 			else
-				hipLaunchKernelGGL(k_gather<false>, grid, dim3(256), 0, s->stream, d, (int)cap[lv], A[lv], B[lv], C[lv], (const float4*)A[lv + 1],
+				hipLaunchKernelGGL(k_gather<false>, grid, dim3(256), 0, s->stream, d, (int)cap[lv], A[lv], B[lv], (const float4*)A[lv + 1],
 								   (const int*)nullptr, (const float4*)nullptr, (unsigned*)nullptr, nDev);
 			HIPCHK(hipGetLastError());
 		}
