@@ -42,6 +42,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -149,6 +150,7 @@ struct rtx_scene {
 	bool instrumented = false;
 	// host copies
 	std::vector<HostTri> tris;
+	int maxTriTex = -1;  // the largest texture id a triangle names (checked against the textures at every call)
 	std::vector<uint8_t> texels;
 	std::vector<TexInfo> texInfo;
 	std::vector<int> rankOf;  // triangle index -> candidate rank
@@ -284,8 +286,7 @@ int ensure_ready(rtx_scene* s, bool needCamera) {
 	if (!s->haveTables) return fail(RTX_ERR_STATE, "rtx_scene_set_tables has not been called");
 	HIPCHK(hipSetDevice(s->device));
 	const int ntex = (int)s->texInfo.size();
-	for (const HostTri& t : s->tris)
-		if (t.tex >= ntex) return fail(RTX_ERR_ARG, "a triangle refers to a texture id that was never added");
+	if (s->maxTriTex >= ntex) return fail(RTX_ERR_ARG, "a triangle refers to a texture id that was never added");
 	if (s->hasSky)
 		for (int i = 0; i < 6; ++i)
 			if (s->skyTex[i] < 0 || s->skyTex[i] >= ntex) return fail(RTX_ERR_ARG, "skybox texture id out of range");
@@ -793,7 +794,9 @@ RTX_API int rtx_scene_set_triangles(rtx_scene* s, const void* triangles, uint32_
 	s->tris.resize(n);
 	if (n) std::memcpy((void*)s->tris.data(), triangles, (size_t)n * sizeof(HostTri));
 	float amax = 0.0f;
+	int maxTex = -1;
 	for (const HostTri& t : s->tris) {
+		maxTex = std::max(maxTex, (int)t.tex);
 		for (int k = 0; k < 3; ++k) {
 			if (!(t.v[k][3] == 0.0f) || !(t.n[k][3] == 0.0f))
 				return fail(RTX_ERR_ARG, "triangle w lanes must be zero, as the reference constructs them");
@@ -807,6 +810,7 @@ RTX_API int rtx_scene_set_triangles(rtx_scene* s, const void* triangles, uint32_
 		if (t.tex < -1) return fail(RTX_ERR_ARG, "texture index below -1");
 	}
 	s->sceneAbsMax = amax;
+	s->maxTriTex = maxTex;
 	s->haveTris = true;
 	s->haveBvh = false;
 	s->haveHistory = false;
