@@ -271,8 +271,9 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 	}
 }
 
-// What a ray of the last level returns, from its any-hit answer (src/RayTracer.cpp:148-152,170): a hit is worth
-// zero, a miss the sky or the background.
+// The rays of the last recursion level end their paths whatever they hit: a hit returns zero
+// (src/RayTracer.cpp:170), a miss the sky or the background (:148-152).  This is that value, from the ray's
+// any-hit answer; -2 marks a slot without a ray, -3 a ray that was not traced because both outcomes are zero.
 __device__ __forceinline__ float3 last_level_value(const DevScene& sc, int code, const float4* __restrict__ rayD, unsigned slot,
 												   unsigned& dead, unsigned& fetches, unsigned& untraced) {
 	float3 val = make_float3(0.0f, 0.0f, 0.0f);
@@ -288,31 +289,6 @@ __device__ __forceinline__ float3 last_level_value(const DevScene& sc, int code,
 			val = make_float3(sc.bg.x, sc.bg.y, sc.bg.z);
 	}
 	return val;
-}
-
-// The rays of the last recursion level end their paths whatever they hit: a hit returns zero
-// (src/RayTracer.cpp:170), a miss the sky or the background (:148-152).  Only A is written (B and C of the
-// last level are never read).  Blocks stride over the queue so that each adds its counts once.  Launched when
-// the last level is the first (max_recursion_depth 0); otherwise k_gather<true> does this on the way.
-__global__ __launch_bounds__(256) void k_shade_last(DevScene sc, const float4* __restrict__ rayD, const float4* __restrict__ hits,
-													int n, float4* __restrict__ A, unsigned* __restrict__ cnt, const unsigned* __restrict__ nDev) {
-	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
-	const int* __restrict__ codes = reinterpret_cast<const int*>(hits);  // any-hit answers: one int per ray
-	unsigned dead = 0, fetches = 0, untraced = 0;
-	for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
-		const float3 val = last_level_value(sc, codes[j], rayD, (unsigned)j, dead, fetches, untraced);
-		A[j] = make_float4(val.x, val.y, val.z, 0.0f);
-	}
-	for (int off = 32; off > 0; off >>= 1) {
-		dead += __shfl_down(dead, off, 64);
-		fetches += __shfl_down(fetches, off, 64);
-		untraced += __shfl_down(untraced, off, 64);
-	}
-	if ((threadIdx.x & 63) == 0) {
-		if (dead) atomicAdd(&cnt[1], dead);
-		if (fetches) atomicAdd(&cnt[3], fetches);
-		if (untraced) atomicAdd(&cnt[2], untraced);  // the slot of the shaded hits, of which this level has none
-	}
 }
 
 // Combine step of RayTracer::color for the nodes of one level, children read from the next

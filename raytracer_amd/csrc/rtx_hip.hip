@@ -494,9 +494,9 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 	level_ratios(s, useHistory, levels, ratio);
 	double sumRatio = 0.0, maxRatio = 0.0;
 	for (int lv = 0; lv <= levels; ++lv) {
-		// the last level keeps no node records unless it is the only one (its values are formed inside the
-		// gather of the level above)
-		if (lv < levels || levels == 0) sumRatio += ratio[lv];
+		// the last level keeps no node records (its values are formed inside the gather of the level above);
+		// levels == 0 is the primary-hit export, which keeps none at all
+		if (lv < levels) sumRatio += ratio[lv];
 		maxRatio = std::max(maxRatio, ratio[lv]);
 	}
 	// per sample: A, B, C of those levels; two ping-pong ray sets and the set-aside list sized for the widest level
@@ -587,7 +587,7 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 		int2* B[MAX_DEPTH + 1];
 		for (int lv = 0; lv <= s->maxDepth; ++lv) {
 			const size_t n = cap[lv];
-			const bool keepsNodes = lv < s->maxDepth || lv == 0;
+			const bool keepsNodes = lv < s->maxDepth;
 			A[lv] = keepsNodes ? (float4*)bump.take(n * 16) : nullptr;
 			B[lv] = keepsNodes ? (int2*)bump.take(n * 8) : nullptr;
 			if (keepsNodes && (!A[lv] || !B[lv])) return fail(RTX_ERR_MEMORY, "work arena exhausted (internal sizing error)");
@@ -596,18 +596,15 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 			rc = launch_trace(s, d, lv == s->maxDepth, false, rayO[cur], rayD[cur], hit[cur], (int)n,
 							  s->dCounts.p + (size_t)lv * CNT_STRIDE, unsafeList, lv, nDev);
 			if (rc) return rc;
+			// the last level (max_recursion_depth >= 1) has no shade pass: the gather of the level above forms
+			// its values from the any-hit answers
+			if (lv == s->maxDepth) break;
 			unsigned* cnt = s->dCounts.p + (size_t)(lv + 1) * CNT_STRIDE;
 			rc = begin_event(s, 1, ev);
 			if (rc) return rc;
-			if (lv == s->maxDepth && lv > 0)
-				;  // the gather of the level above reads the any-hit answers itself
-			else if (lv == s->maxDepth)
-				hipLaunchKernelGGL(k_shade_last, dim3((unsigned)std::min<size_t>((n + 255) / 256, (size_t)s->numCUs * 8)), dim3(256), 0, s->stream,
-								   d, rayD[cur], hit[cur], (int)n, A[lv], cnt, nDev);
-			else
-				hipLaunchKernelGGL(k_shade, dim3((unsigned)std::min<size_t>((n + SHADE_THREADS - 1) / SHADE_THREADS, (size_t)s->numCUs * 4)), dim3(SHADE_THREADS), 0, s->stream, d, lv,
-								   rayO[cur], rayD[cur], hit[cur], (int)n, A[lv], B[lv], rayO[nxt], rayD[nxt], cnt, (unsigned)cap[lv + 1],
-								   nDev);
+			hipLaunchKernelGGL(k_shade, dim3((unsigned)std::min<size_t>((n + SHADE_THREADS - 1) / SHADE_THREADS, (size_t)s->numCUs * 4)), dim3(SHADE_THREADS), 0, s->stream, d, lv,
+							   rayO[cur], rayD[cur], hit[cur], (int)n, A[lv], B[lv], rayO[nxt], rayD[nxt], cnt, (unsigned)cap[lv + 1],
+							   nDev);
 			HIPCHK(hipGetLastError());
 			rc = end_event(s, ev);
 			if (rc) return rc;
