@@ -7,8 +7,9 @@ immutable scene and renders a share of the 64x64-pixel tiles.  There is no colle
 path of a frame.  One exchange step produces the image on rank 0:
 
   static  tile t belongs to rank t % world (interleaved, so expensive regions are spread);
-          every rank packs the accumulators of its own tiles and rank 0 receives them with one
-          gather -- each peer sends only its 1/world of the image over its own direct link.
+          every rank packs the accumulators of its own tiles (one index_select over a cached pixel
+          index) and rank 0 receives them with one gather -- each peer sends only its 1/world of the
+          image over its own direct link -- and scatters them into the image with one index_copy.
   dynamic ranks pull batches of tiles from a shared counter (the rendezvous store's atomic add),
           render each frame into a zeroed frame buffer, and the frame buffers are sum-reduced to
           rank 0, which adds the frame to its accumulator.  Every pixel is non-zero on exactly one
@@ -24,20 +25,6 @@ TILE = 64
 
 def tile_grid(width, height):
     return (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
-
-
-def _as_tiles(img, tiles_x, tiles_y):
-    """(H,W,4) -> (tiles, TILE, TILE, 4) with zero padding at the right/bottom edges."""
-    h, w, c = img.shape
-    pad = img.new_zeros((tiles_y * TILE, tiles_x * TILE, c))
-    pad[:h, :w] = img
-    return pad.view(tiles_y, TILE, tiles_x, TILE, c).permute(0, 2, 1, 3, 4).reshape(tiles_x * tiles_y, TILE, TILE, c)
-
-
-def _from_tiles(tiles, tiles_x, tiles_y, width, height):
-    c = tiles.shape[-1]
-    pad = tiles.view(tiles_y, tiles_x, TILE, TILE, c).permute(0, 2, 1, 3, 4).reshape(tiles_y * TILE, tiles_x * TILE, c)
-    return pad[:height, :width].contiguous()
 
 
 class TileSharder:
@@ -58,22 +45,46 @@ class TileSharder:
         rank = self.rank if rank is None else rank
         return torch.arange(rank, self.n_tiles, self.world)
 
+    def _pixel_index(self, rank):
+        """Flat pixel indices of the per_rank tile slots of `rank`, TILE*TILE each; pixels beyond the image and
+        slots beyond the rank's share get the index H*W (one past the image)."""
+        n_pix = self.width * self.height
+        t = self.owned(rank)
+        ty, tx = t // self.tiles_x, t % self.tiles_x
+        yy = (ty[:, None, None] * TILE + torch.arange(TILE)[None, :, None]).expand(len(t), TILE, TILE)
+        xx = (tx[:, None, None] * TILE + torch.arange(TILE)[None, None, :]).expand(len(t), TILE, TILE)
+        idx = torch.where((yy < self.height) & (xx < self.width), yy * self.width + xx, torch.full_like(yy, n_pix))
+        full = torch.full((self.per_rank, TILE, TILE), n_pix, dtype=torch.int64)
+        full[:len(t)] = idx
+        return full.reshape(-1)
+
+    def _plan(self, device):
+        """Index tensors of the exchange, built once per device: what this rank packs, and where rank 0 puts what
+        it receives (row H*W of its staging image swallows the padding)."""
+        cache = self.__dict__.setdefault("_plans", {})
+        key = str(device)
+        if key not in cache:
+            n_pix = self.width * self.height
+            pack = self._pixel_index(self.rank).clamp(max=n_pix - 1).to(device)
+            place = torch.cat([self._pixel_index(r) for r in range(self.world)]).to(device) if self.rank == 0 else None
+            cache[key] = (pack, place)
+        return cache[key]
+
     def gather_static(self, accum):
-        """accum: (H,W,4) tensor holding this rank's tiles.  Returns the whole image on rank 0, None elsewhere."""
+        """accum: (H,W,4) tensor holding this rank's tiles.  Returns the whole image on rank 0, None elsewhere.
+        One packing gather per rank, one collective, one scatter on rank 0."""
         if self.world == 1:
             return accum
-        tiles = _as_tiles(accum, self.tiles_x, self.tiles_y)
-        mine = self.owned().to(accum.device)
-        send = accum.new_zeros((self.per_rank, TILE, TILE, accum.shape[-1]))
-        send[:len(mine)] = tiles.index_select(0, mine)
+        c = accum.shape[-1]
+        n_pix = self.width * self.height
+        pack, place = self._plan(accum.device)
+        send = accum.reshape(n_pix, c).index_select(0, pack)  # padding slots carry some pixel; rank 0 drops them
         if self.rank == 0:
-            recv = [torch.empty_like(send) for _ in range(self.world)]
-            dist.gather(send, recv, dst=0, group=self.group)
-            out = accum.new_zeros((self.n_tiles, TILE, TILE, accum.shape[-1]))
-            for r in range(self.world):
-                idx = self.owned(r).to(accum.device)
-                out.index_copy_(0, idx, recv[r][:len(idx)])
-            return _from_tiles(out, self.tiles_x, self.tiles_y, self.width, self.height)
+            big = accum.new_empty((self.world, send.shape[0], c))
+            dist.gather(send, list(big.unbind(0)), dst=0, group=self.group)
+            out = accum.new_empty((n_pix + 1, c))
+            out.index_copy_(0, place, big.reshape(-1, c))
+            return out[:n_pix].reshape(self.height, self.width, c)
         dist.gather(send, None, dst=0, group=self.group)
         return None
 

@@ -86,10 +86,32 @@ def test_two_rank_static_gather_and_dynamic_reduce(tmp_path):
     assert np.load(out + "_pulled.npy")[0] == 3 * sh.n_tiles
 
 
-def test_tile_views_roundtrip():
-    from raytracer_amd.dist import _as_tiles, _from_tiles
+def test_tile_ownership():
     sh = TileSharder(W, H)
-    img = torch.rand((H, W, 4))
-    back = _from_tiles(_as_tiles(img, sh.tiles_x, sh.tiles_y), sh.tiles_x, sh.tiles_y, W, H)
-    assert torch.equal(img, back)
     assert sh.n_tiles == 12 and TileSharder(W, H, 1, 2).owned().tolist() == [1, 3, 5, 7, 9, 11]
+
+
+def test_static_plan_with_uneven_shares():
+    """12 tiles over 5 ranks: shares of 3, 3, 2, 2, 2 in slots of 3; the exchange of gather_static done by hand
+    (pack on every rank, place on rank 0) must rebuild the image exactly and leave the padding in the dummy row."""
+    world = 5
+    img = torch.rand((H, W, 4))
+    n_pix = W * H
+    sends = []
+    for r in range(world):
+        sh = TileSharder(W, H, r, world)
+        pack, place = sh._plan("cpu")
+        assert (place is None) == (r != 0)
+        mine = torch.zeros_like(img)            # a rank's accumulator: its own tiles only
+        for t in sh.owned().tolist():
+            ty, tx = divmod(t, sh.tiles_x)
+            mine[ty * TILE:(ty + 1) * TILE, tx * TILE:(tx + 1) * TILE] = img[ty * TILE:(ty + 1) * TILE, tx * TILE:(tx + 1) * TILE]
+        sends.append(mine.reshape(n_pix, 4).index_select(0, pack))
+    sh0 = TileSharder(W, H, 0, world)
+    _, place = sh0._plan("cpu")
+    assert sh0.per_rank == 3 and place.numel() == world * 3 * TILE * TILE
+    real = place[place < n_pix]
+    assert real.numel() == n_pix and torch.equal(real.sort().values, torch.arange(n_pix))   # every pixel exactly once
+    out = torch.empty((n_pix + 1, 4))
+    out.index_copy_(0, place, torch.cat(sends))
+    assert torch.equal(out[:n_pix].reshape(H, W, 4), img)
