@@ -45,6 +45,7 @@ struct DevScene {
 	uint32_t seedKey;
 	float sceneAbsMax;
 	int tilesX;
+	int nWide, nTris;  // record counts of `wide` and of the triangle arrays (bounds checks of debug builds)
 };
 
 // ------------------------------------------------------------------------------------------------

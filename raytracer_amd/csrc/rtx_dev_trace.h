@@ -481,6 +481,12 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 		}
 		if (leafPhase) {
 			// exact box of the triangle, exact slab predicate, exact triangle test; one leaf per lane and pass
+#ifdef RTX_BOUNDS_CHECK
+			if (busy && pend0 >= 0 && (unsigned)pend0 >= (unsigned)sc.nTris) {
+				printf("[rtx] k_trace_wide: leaf %d of %d (ray %d, sp %d, cur %d, pend1 %d)\n", pend0, sc.nTris, j, sp, cur, pend1);
+				pend0 = pend1 = -1; cur = -1; sp = 0;
+			}
+#endif
 			if (busy && pend0 >= 0) {
 				const float4* T = sc.triHit + (size_t)pend0 * 4;
 				float4 q0 = T[0], q1 = T[1], q2 = T[2];
@@ -524,6 +530,16 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 		}
 		else if (canWalk) {
 			int item = 0;  // what this lane looks at next: > 0 node, < 0 ~rank of a leaf, 0 nothing yet
+#ifdef RTX_BOUNDS_CHECK
+			if (cur >= sc.nWide) {
+				printf("[rtx] k_trace_wide: node %d of %d (ray %d, sp %d, pend %d %d)\n", cur, sc.nWide, j, sp, pend0, pend1);
+				cur = -1; sp = 0;
+			}
+			if (sp < 0 || sp > STACK) {
+				printf("[rtx] k_trace_wide: stack pointer %d (ray %d)\n", sp, j);
+				sp = 0;
+			}
+#endif
 			if (cur >= 0) {
 				const float4* W = sc.wide + (size_t)cur * 4;
 				float4 w0 = W[0], w1 = W[1], w2 = W[2], w3 = W[3];

@@ -259,6 +259,8 @@ DevScene make_dev_scene(const rtx_scene* s) {
 	d.seedKey = mix((uint32_t)s->seed, (uint32_t)(s->seed >> 32));
 	d.sceneAbsMax = s->sceneAbsMax;
 	d.tilesX = (s->width + TILE - 1) / TILE;
+	d.nWide = (int)s->numWide;
+	d.nTris = (int)s->tris.size();
 	return d;
 }
 
