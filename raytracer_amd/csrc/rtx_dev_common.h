@@ -29,8 +29,8 @@ struct DevScene {
 	const float4* pairs;     // 4 x float4 per child pair: Lmin|codeL, Lmax|-, Rmin|codeR, Rmax|-
 	const float4* wide;      // 4 x float4 per node of the 4-wide quantised collapse of the tree
 	const float4* triHit;    // 4 x float4 per triangle in candidate-rank order: n, v0, v1, v2, index
-	const float4* triShade;  // 4 x float4 per triangle in candidate-rank order: n0 r | n1 g | n2 b | rough ior tex flags
-	const float4* triUv;     // 2 x float4 per triangle: uv0 uv1 | uv2 - -   (read for textured hits only)
+	const float4* triShade;  // 8 x float4 (one 128-byte line) per triangle in candidate-rank order:
+	                         // n0 r | n1 g | n2 b | rough ior tex flags | uv0 uv1 | uv2 - - | - | -
 	const uint8_t* texels;
 	const int4* texDesc;     // byte offset, width, height
 	const float* cosT;
@@ -45,8 +45,14 @@ struct DevScene {
 	uint32_t seedKey;
 	float sceneAbsMax;
 	int tilesX;
-	int nWide, nTris;  // record counts of `wide` and of the triangle arrays (bounds checks of debug builds)
+	int nWide, nTris, nTex;  // record counts of `wide`, of the triangle arrays and of texDesc
+	unsigned* fault;         // one word: a kernel that meets an index outside those counts sets a bit and skips
 };
+
+// Bits of DevScene::fault.  An index is checked wherever it comes out of a queue record and is about to address
+// scene data: a record nobody wrote must end in an error code, never in an access outside the arrays.
+constexpr unsigned FAULT_HIT_RANK = 1u, FAULT_TEX_ID = 2u, FAULT_CHILD_SLOT = 4u, FAULT_NODE = 8u, FAULT_LEAF = 16u,
+				   FAULT_STACK = 32u;
 
 // ------------------------------------------------------------------------------------------------
 // Small device helpers.  dot4 is Eigen's reduction order with the (zero) w lane kept as "+ 0.0f".

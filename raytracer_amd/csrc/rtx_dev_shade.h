@@ -97,11 +97,14 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 				else
 					val = make_float3(sc.bg.x, sc.bg.y, sc.bg.z);
 			}
+			else if ((unsigned)rank >= (unsigned)sc.nTris) {
+				atomicOr(sc.fault, FAULT_HIT_RANK);  // not a hit record: worth nothing, reported to the host
+			}
 			else if (level < sc.maxDepth) {
 				// (at level == maxDepth every hit returns zero, src/RayTracer.cpp:170; the any-hit
 				//  traversal reports such hits with rank 0, which is never dereferenced)
 				// one aligned 64-byte record serves every hit; the texture coordinates live apart
-				const float4* T = sc.triShade + (size_t)rank * 4;
+				const float4* T = sc.triShade + (size_t)rank * 8;
 				float4 s0 = T[0], s1 = T[1], s2 = T[2], s3 = T[3];
 				const float t = H.y, alpha = H.z, beta = H.w;
 				const int triFlags = __float_as_int(s3.w);
@@ -145,9 +148,10 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 						kind = KIND_DIEL;
 						nchild = S + Dn;
 						scalar = fabsf(cosine);
-						if (texId >= 0) {
+						if (texId >= sc.nTex) atomicOr(sc.fault, FAULT_TEX_ID);
+						else if (texId >= 0) {
 							flags |= FLAG_TEX;
-							const float4 u01 = sc.triUv[(size_t)rank * 2], u2 = sc.triUv[(size_t)rank * 2 + 1];
+							const float4 u01 = T[4], u2 = T[5];
 							float u = (alpha * u01.x + beta * u01.z) + g * u2.x;
 							float v = (alpha * u01.y + beta * u01.w) + g * u2.y;
 							texel = tex_fetch_rgb(sc, texId, u, v);
@@ -301,7 +305,7 @@ template <bool LAST>
 __global__ __launch_bounds__(256) void k_gather(DevScene sc, int n, float4* __restrict__ A, const int2* __restrict__ B,
 												const float4* __restrict__ childA,
 												const int* __restrict__ codes, const float4* __restrict__ childD,
-												unsigned* __restrict__ cnt, const unsigned* __restrict__ nDev) {
+												unsigned childCap, unsigned* __restrict__ cnt, const unsigned* __restrict__ nDev) {
 	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
 	const int S = sc.nSpec, Dn = sc.nDiff;
 	unsigned dead = 0, fetches = 0, untraced = 0;
@@ -311,6 +315,11 @@ __global__ __launch_bounds__(256) void k_gather(DevScene sc, int n, float4* __re
 		if (kind == KIND_LEAF) continue;
 		const float4 col = A[j];
 		const unsigned first = (unsigned)b.x;
+		const unsigned nchild = (unsigned)(kind == KIND_METAL ? S : kind == KIND_TRANSP ? S + 1 : S + Dn);
+		if (first > childCap || nchild > childCap - first) {
+			atomicOr(sc.fault, FAULT_CHILD_SLOT);  // not a node record: left as it is, reported to the host
+			continue;
+		}
 		float sx = 0.0f, sy = 0.0f, sz = 0.0f;
 		for (int i = 0; i < S; ++i) {
 			float3 c;
@@ -504,6 +513,10 @@ __global__ __launch_bounds__(256) void k_export_hits(DevScene sc, Batch b, const
 	float4 h = hits[j];
 	int rank = __float_as_int(h.x);
 	size_t o = ((size_t)y * sc.width + x) * 4 + sub;
+	if (rank >= sc.nTris) {
+		atomicOr(sc.fault, FAULT_HIT_RANK);
+		rank = -1;
+	}
 	ids[o] = rank >= 0 ? __float_as_int(sc.triHit[(size_t)rank * 4 + 3].x) : -1;
 	if (tab) {
 		tab[o * 3 + 0] = h.y;
@@ -518,6 +531,10 @@ __global__ __launch_bounds__(256) void k_export_hits_linear(DevScene sc, int n, 
 	if (j >= n) return;
 	float4 h = hits[j];
 	int rank = __float_as_int(h.x);
+	if (rank >= sc.nTris) {
+		atomicOr(sc.fault, FAULT_HIT_RANK);
+		rank = -1;
+	}
 	ids[j] = rank >= 0 ? __float_as_int(sc.triHit[(size_t)rank * 4 + 3].x) : -1;
 	if (tab) {
 		tab[(size_t)j * 3 + 0] = h.y;

@@ -484,6 +484,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 #ifdef RTX_BOUNDS_CHECK
 			if (busy && pend0 >= 0 && (unsigned)pend0 >= (unsigned)sc.nTris) {
 				printf("[rtx] k_trace_wide: leaf %d of %d (ray %d, sp %d, cur %d, pend1 %d)\n", pend0, sc.nTris, j, sp, cur, pend1);
+				atomicOr(sc.fault, FAULT_LEAF);
 				pend0 = pend1 = -1; cur = -1; sp = 0;
 			}
 #endif
@@ -533,10 +534,12 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 #ifdef RTX_BOUNDS_CHECK
 			if (cur >= sc.nWide) {
 				printf("[rtx] k_trace_wide: node %d of %d (ray %d, sp %d, pend %d %d)\n", cur, sc.nWide, j, sp, pend0, pend1);
+				atomicOr(sc.fault, FAULT_NODE);
 				cur = -1; sp = 0;
 			}
 			if (sp < 0 || sp > STACK) {
 				printf("[rtx] k_trace_wide: stack pointer %d (ray %d)\n", sp, j);
+				atomicOr(sc.fault, FAULT_STACK);
 				sp = 0;
 			}
 #endif

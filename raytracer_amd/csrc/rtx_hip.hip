@@ -168,7 +168,7 @@ struct rtx_scene {
 	uint32_t numWide = 0;
 	uint32_t numPairs = 0;
 	// device
-	DevBuf<float4> dPairs, dWide, dTriHit, dTriShade, dTriUv;
+	DevBuf<float4> dPairs, dWide, dTriHit, dTriShade;
 	DevBuf<unsigned> dToneBits;
 	DevBuf<unsigned char> dToneVal, dRgb8;
 	int toneN = 0;
@@ -189,7 +189,7 @@ struct rtx_scene {
 
 	~rtx_scene() {
 		(void)hipSetDevice(device);
-		dPairs.release(); dWide.release(); dTriHit.release(); dTriShade.release(); dTriUv.release(); dToneBits.release(); dToneVal.release(); dRgb8.release(); dTexels.release(); dTexDesc.release();
+		dPairs.release(); dWide.release(); dTriHit.release(); dTriShade.release(); dToneBits.release(); dToneVal.release(); dRgb8.release(); dTexels.release(); dTexDesc.release();
 		dTables.release(); dAccumOwn.release(); arena.release(); dCounts.release(); dStats.release();
 		if (hCounts) (void)hipHostFree(hCounts);
 		if (hStats) (void)hipHostFree(hStats);
@@ -205,6 +205,15 @@ namespace {
 
 constexpr int MAX_DEPTH = 15;
 constexpr int CNT_STRIDE = 8;   // per level: 0 queue length, 1 dead, 2 shaded, 3 texel fetches, 4 overflow flag, 5-7 trace cursors
+constexpr int FAULT_WORD = (MAX_DEPTH + 2) * CNT_STRIDE;  // behind the level blocks: the kernels' consistency checks (DevScene::fault)
+constexpr int COUNT_WORDS = FAULT_WORD + CNT_STRIDE;
+
+// The kernels' consistency word (DevScene::fault) as read back after the stream has drained.
+int check_fault(unsigned bits) {
+	if (!bits) return RTX_OK;
+	return fail(RTX_ERR_DEVICE, "device consistency check failed (fault bits " + std::to_string(bits) +
+									"): a queue record held an index outside the scene; the image of this call is not valid");
+}
 
 int num_tiles(const rtx_scene* s) {
 	int tx = (s->width + TILE - 1) / TILE, ty = (s->height + TILE - 1) / TILE;
@@ -227,7 +236,6 @@ DevScene make_dev_scene(const rtx_scene* s) {
 	d.wide = s->dWide.p;
 	d.triHit = s->dTriHit.p;
 	d.triShade = s->dTriShade.p;
-	d.triUv = s->dTriUv.p;
 	d.texels = s->dTexels.p;
 	d.texDesc = s->dTexDesc.p;
 	d.cosT = s->dTables.p;
@@ -261,6 +269,8 @@ DevScene make_dev_scene(const rtx_scene* s) {
 	d.tilesX = (s->width + TILE - 1) / TILE;
 	d.nWide = (int)s->numWide;
 	d.nTris = (int)s->tris.size();
+	d.nTex = (int)s->texInfo.size();
+	d.fault = s->dCounts.p + FAULT_WORD;
 	return d;
 }
 
@@ -304,9 +314,9 @@ int ensure_ready(rtx_scene* s, bool needCamera) {
 		s->stream = s->ownStream;
 	}
 	if (!s->dCounts.p) {
-		HIPCHK(s->dCounts.alloc((MAX_DEPTH + 2) * CNT_STRIDE));
+		HIPCHK(s->dCounts.alloc(COUNT_WORDS));
 		HIPCHK(s->dStats.alloc(12));
-		HIPCHK(hipHostMalloc((void**)&s->hCounts, (MAX_DEPTH + 2) * CNT_STRIDE * sizeof(unsigned), hipHostMallocDefault));
+		HIPCHK(hipHostMalloc((void**)&s->hCounts, COUNT_WORDS * sizeof(unsigned), hipHostMallocDefault));
 		HIPCHK(hipHostMalloc((void**)&s->hStats, 12 * sizeof(unsigned long long), hipHostMallocDefault));
 	}
 	return RTX_OK;
@@ -564,7 +574,7 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 		float4* rayD[2] = {(float4*)(bump.base + bump.hi + setBytes), (float4*)(bump.base + bump.hi + 4 * setBytes)};
 		float4* hit[2] = {(float4*)(bump.base + bump.hi + 2 * setBytes), (float4*)(bump.base + bump.hi + 5 * setBytes)};
 
-		HIPCHK(hipMemsetAsync(s->dCounts.p, 0, (MAX_DEPTH + 2) * CNT_STRIDE * sizeof(unsigned), s->stream));
+		HIPCHK(hipMemsetAsync(s->dCounts.p, 0, COUNT_WORDS * sizeof(unsigned), s->stream));
 		size_t ev;
 		rc = begin_event(s, 1, ev);
 		if (rc) return rc;
@@ -578,7 +588,10 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 			if (rc) return rc;
 			hipLaunchKernelGGL(k_export_hits, dim3((b.nSamples + 255) / 256), dim3(256), 0, s->stream, d, b, hit[0], tg.dIds, tg.dTab);
 			HIPCHK(hipGetLastError());
+			HIPCHK(hipMemcpyAsync(s->hCounts + FAULT_WORD, s->dCounts.p + FAULT_WORD, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
 			HIPCHK(hipStreamSynchronize(s->stream));
+			rc = check_fault(s->hCounts[FAULT_WORD]);
+			if (rc) return rc;
 			continue;
 		}
 
@@ -620,11 +633,11 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 				// the children are the last level: its rays and any-hit answers lie in the buffers of its parity
 				const int last = s->maxDepth & 1;
 				hipLaunchKernelGGL(k_gather<true>, grid, dim3(256), 0, s->stream, d, (int)cap[lv], A[lv], B[lv], (const float4*)nullptr,
-								   (const int*)hit[last], (const float4*)rayD[last], s->dCounts.p + (size_t)(s->maxDepth + 1) * CNT_STRIDE, nDev);
+								   (const int*)hit[last], (const float4*)rayD[last], (unsigned)cap[lv + 1], s->dCounts.p + (size_t)(s->maxDepth + 1) * CNT_STRIDE, nDev);
 			}
 			else
 				hipLaunchKernelGGL(k_gather<false>, grid, dim3(256), 0, s->stream, d, (int)cap[lv], A[lv], B[lv], (const float4*)A[lv + 1],
-								   (const int*)nullptr, (const float4*)nullptr, (unsigned*)nullptr, nDev);
+								   (const int*)nullptr, (const float4*)nullptr, (unsigned)cap[lv + 1], (unsigned*)nullptr, nDev);
 			HIPCHK(hipGetLastError());
 		}
 		const int npix = b.nSamples / 4;
@@ -635,7 +648,7 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 		HIPCHK(hipGetLastError());
 		rc = end_event(s, ev);
 		if (rc) return rc;
-		HIPCHK(hipMemcpyAsync(s->hCounts, s->dCounts.p, (MAX_DEPTH + 2) * CNT_STRIDE * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+		HIPCHK(hipMemcpyAsync(s->hCounts, s->dCounts.p, COUNT_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
 		HIPCHK(hipStreamSynchronize(s->stream));
 		rc = harvest_events(s);
 		if (rc) return rc;
@@ -654,6 +667,8 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 			if (rc) return rc;
 			continue;
 		}
+		rc = check_fault(s->hCounts[FAULT_WORD]);
+		if (rc) return rc;
 		s->haveHistory = true;
 		uint64_t n = (uint64_t)b.nSamples;
 		for (int lv = 0; lv <= s->maxDepth; ++lv) {
@@ -969,8 +984,7 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 					 (int)wideOk, wide.size() / 16, wideStackNeed, npairs, maxInteriorDepth + 1);
 
 	// Triangle records in rank order.
-	std::vector<float4> th((size_t)std::max<uint32_t>(ntri, 1) * 4), ts((size_t)std::max<uint32_t>(ntri, 1) * 4),
-		tu((size_t)std::max<uint32_t>(ntri, 1) * 2);
+	std::vector<float4> th((size_t)std::max<uint32_t>(ntri, 1) * 4), ts((size_t)std::max<uint32_t>(ntri, 1) * 8);
 	for (uint32_t i = 0; i < ntri; ++i) {
 		const HostTri& t = s->tris[i];
 		const size_t r = (size_t)rankOf[i];
@@ -993,12 +1007,12 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 		float texf, flagf;
 		std::memcpy(&texf, &t.tex, 4);
 		std::memcpy(&flagf, &flags, 4);
-		ts[r * 4 + 0] = make_float4(t.n[0][0], t.n[0][1], t.n[0][2], t.color[0]);
-		ts[r * 4 + 1] = make_float4(t.n[1][0], t.n[1][1], t.n[1][2], t.color[1]);
-		ts[r * 4 + 2] = make_float4(t.n[2][0], t.n[2][1], t.n[2][2], t.color[2]);
-		ts[r * 4 + 3] = make_float4(t.rough, t.ior, texf, flagf);
-		tu[r * 2 + 0] = make_float4(t.uv[0][0], t.uv[0][1], t.uv[1][0], t.uv[1][1]);
-		tu[r * 2 + 1] = make_float4(t.uv[2][0], t.uv[2][1], 0.0f, 0.0f);
+		ts[r * 8 + 0] = make_float4(t.n[0][0], t.n[0][1], t.n[0][2], t.color[0]);
+		ts[r * 8 + 1] = make_float4(t.n[1][0], t.n[1][1], t.n[1][2], t.color[1]);
+		ts[r * 8 + 2] = make_float4(t.n[2][0], t.n[2][1], t.n[2][2], t.color[2]);
+		ts[r * 8 + 3] = make_float4(t.rough, t.ior, texf, flagf);
+		ts[r * 8 + 4] = make_float4(t.uv[0][0], t.uv[0][1], t.uv[1][0], t.uv[1][1]);
+		ts[r * 8 + 5] = make_float4(t.uv[2][0], t.uv[2][1], 0.0f, 0.0f);
 	}
 
 	HIPCHK(hipSetDevice(s->device));
@@ -1015,8 +1029,6 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 	HIPCHK(hipMemcpy(s->dTriHit.p, th.data(), th.size() * sizeof(float4), hipMemcpyHostToDevice));
 	HIPCHK(s->dTriShade.alloc(ts.size()));
 	HIPCHK(hipMemcpy(s->dTriShade.p, ts.data(), ts.size() * sizeof(float4), hipMemcpyHostToDevice));
-	HIPCHK(s->dTriUv.alloc(tu.size()));
-	HIPCHK(hipMemcpy(s->dTriUv.p, tu.data(), tu.size() * sizeof(float4), hipMemcpyHostToDevice));
 	s->rankOf.swap(rankOf);
 	s->numPairs = (uint32_t)npairs;
 	s->treeDepth = maxDepth + 1;  // + the root-only pair
@@ -1241,11 +1253,14 @@ RTX_API int rtx_trace_rays(rtx_scene* s, int mode, uint32_t n, const float* orig
 	if (e == hipSuccess) {
 		const DevScene d = make_dev_scene(s);
 		e = hipMemsetAsync(s->dCounts.p, 0, CNT_STRIDE * sizeof(unsigned), s->stream);
+		if (e == hipSuccess) e = hipMemsetAsync(s->dCounts.p + FAULT_WORD, 0, sizeof(unsigned), s->stream);
 		if (e == hipSuccess) rc = launch_trace(s, d, false, mode == 1, dO.p, dD.p, dH.p, (int)n, s->dCounts.p, dList.p);
 		if (rc == RTX_OK) {
 			hipLaunchKernelGGL(k_export_hits_linear, dim3((n + 255) / 256), dim3(256), 0, s->stream, d, (int)n, dH.p, dIds.p, dTab.p);
 			e = hipGetLastError();
 			if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+			if (e == hipSuccess) e = hipMemcpy(s->hCounts + FAULT_WORD, s->dCounts.p + FAULT_WORD, sizeof(unsigned), hipMemcpyDeviceToHost);
+			if (e == hipSuccess) rc = check_fault(s->hCounts[FAULT_WORD]);
 			if (e == hipSuccess) e = hipMemcpy(tri_ids, dIds.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
 			if (e == hipSuccess && t_alpha_beta) e = hipMemcpy(t_alpha_beta, dTab.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost);
 		}
