@@ -8,8 +8,11 @@ A step is one frame (one iteration of the loop at /root/reference/src/RayTracer.
 samples per pixel through the whole bounce loop, accumulated) of the Sponza-class procedural atrium
 (~263k triangles, textures, cube-map sky) at 1920x1080, max_recursion_depth 4, one diffuse and one
 specular ray per hit -- BASELINE config 3.  The scene, textures and BVH are resident on the GPU before
-the timed region; with N > 1 the image tiles are interleaved over the ranks (fixed total work:
-strong scaling) and every step ends with the RCCL gather of the tile accumulators to rank 0.
+the timed region.  With N > 1 the image tiles are interleaved over the ranks and a step is N consecutive
+frames, so every rank keeps the work of one whole frame per step (weak scaling: its 1/N tile share of N frames,
+which the library renders as one merged pixel batch); --scaling strong keeps one frame per step instead.
+There is no collective inside a step's rendering; every step ends with the RCCL gather of the tile
+accumulators to rank 0.
 
 Prints one JSON line on rank 0.  `value` is Mrays/s over all ranks: color()-equivalent ray
 queries (primary, secondary, last-depth occlusion) divided by the wall time of the K steps.
@@ -93,6 +96,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--balance", choices=["static", "dynamic"], default="static")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: a step is N frames on N GPUs (fixed work per GPU); strong: a step is one frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-instrument", action="store_true")
     args = ap.parse_args()
@@ -140,9 +145,11 @@ def main():
         counters["fetches"] += st["texture_fetches"]
         counters["untraced"] += st["rays_untraced"]
 
+    frames_per_step = world if (args.scaling == "weak" and args.balance == "static") else 1
+
     def step(frame):
         if args.balance == "static":
-            rt.render(frame, 1)
+            rt.render(frame, frames_per_step)
             take_stats()
             sharder.gather_static(accum)
         else:
@@ -168,14 +175,14 @@ def main():
     frame = 1
     for _ in range(args.warmup):
         step(frame)
-        frame += 1
+        frame += frames_per_step
     for k in counters:
         counters[k] = 0
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(frame)
-        frame += 1
+        frame += frames_per_step
     sync()
     dt = time.perf_counter() - t0
 
@@ -194,7 +201,7 @@ def main():
     n_node = n_tri = n_wide = n_leaf = None
     if not args.no_instrument and args.balance == "static":
         rt.set_instrumented(True)
-        rt.render(frame - 1, 1)
+        rt.render(frame - frames_per_step, frames_per_step)
         st = rt.stats()
         rt.set_instrumented(False)
         n_node = st["node_tests"] / max(st["rays"], 1)
@@ -203,13 +210,14 @@ def main():
         n_leaf = st["leaf_fetches"] / max(st["rays"], 1)
 
     if rank == 0:
-        samples = sc.width * sc.height * 4 * args.steps
+        samples = sc.width * sc.height * 4 * args.steps * frames_per_step
         out = {
             "metric": "Mrays/s (incl. secondary) at 1080p", "value": round(rays_total / dt / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if frames_per_step == world else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "atrium (Sponza-class, %d triangles, %d textures + cube-map sky) %dx%d, 4 spp per step, "
                                    "max_recursion_depth %d, diffuse 1, specular 1" % (len(sc.tris), len(sc.textures), sc.width, sc.height, sc.max_depth),
+                       "frames_per_step": frames_per_step,
                        "sharding": "tile-interleave x%d, %s" % (world, "gather to rank 0 per step" if args.balance == "static" else "dynamic batches + reduce per step")},
             "samples_per_s": round(samples / dt, 1),
             "rays_per_step": round(rays_total / args.steps),

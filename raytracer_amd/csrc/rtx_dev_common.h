@@ -182,18 +182,27 @@ __device__ __forceinline__ bool miss_is_zero(const DevScene& sc, float dx, float
 
 // ------------------------------------------------------------------------------------------------
 // Level-0 sample order.  Sample j of a batch that starts at pixel block g0:
-//   block g = g0 + j/64 -> (tile slot, block in tile); lane = j%64 -> (pixel in block, sub-sample).
+//   block G = g0 + j/64 -> (frame G / blocksPerFrame, block g = G % blocksPerFrame of the scene's tile list)
+//   g -> (tile slot, block in tile); lane = j%64 -> (pixel in block, sub-sample).
 // A wave therefore holds the 4 sub-samples of a 4x4 pixel block, which keeps primary rays of
 // one wave spatially adjacent.  Tiles are taken from the arithmetic list first + k*stride.
+// Consecutive frames follow one another in the block numbering, so one batch may hold pixel blocks of
+// several frames: a small tile share then still fills the queues.
 
 struct Batch {
-	int g0;          // first pixel block (global over the scene's tile list)
-	int nSamples;    // (number of blocks) * 64
+	int g0;              // first pixel block (numbered over the frames of the call, then over the scene's tile list)
+	int nSamples;        // (number of blocks) * 64
 	int tileFirst, tileStride;
+	int blocksPerFrame;  // pixel blocks of the scene's tile list
+	uint32_t frame0;     // the frame that block 0 belongs to
 };
 
-__device__ __forceinline__ bool sample_to_pixel(const DevScene& sc, const Batch& b, int j, int& x, int& y, int& sub) {
-	int g = b.g0 + (j >> 6);
+__device__ __forceinline__ bool sample_to_pixel(const DevScene& sc, const Batch& b, int j, int& x, int& y, int& sub,
+												uint32_t* frame = nullptr) {
+	const int G = b.g0 + (j >> 6);
+	const int f = G / b.blocksPerFrame;
+	int g = G - f * b.blocksPerFrame;
+	if (frame) *frame = b.frame0 + (uint32_t)f;
 	int lane = j & 63;
 	int slot = g / BLOCKS_PER_TILE;
 	int blk = g - slot * BLOCKS_PER_TILE;

@@ -6,12 +6,13 @@
 namespace {
 
 // Camera::getRay (src/Camera.cpp:37-49) plus the per-sample RNG key.
-__global__ __launch_bounds__(256) void k_raygen(DevScene sc, Batch b, uint32_t frame, float4* __restrict__ rayO,
+__global__ __launch_bounds__(256) void k_raygen(DevScene sc, Batch b, float4* __restrict__ rayO,
 												float4* __restrict__ rayD) {
 	int j = blockIdx.x * 256 + threadIdx.x;
 	if (j >= b.nSamples) return;
 	int x, y, sub;
-	bool valid = sample_to_pixel(sc, b, j, x, y, sub);
+	uint32_t frame;
+	bool valid = sample_to_pixel(sc, b, j, x, y, sub, &frame);
 	if (!valid) {
 		rayO[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		rayD[j] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);  // w = 1 marks a dead slot
@@ -407,6 +408,8 @@ __global__ __launch_bounds__(256) void k_gather(DevScene sc, int n, float4* __re
 }
 
 // accumulateImg(row,col) += (c0+c1+c2+c3) * 0.25f (src/RayTracer.cpp:242-246).  One thread per pixel.
+// `b` must lie within one frame: the host launches this once per frame a batch touches, in frame order, so a
+// pixel receives its frames in the order of the reference's loop (src/RayTracer.cpp:234).
 // True when some level's child queue was too small for this batch (slot 4 of the counter blocks): the batch's
 // result is then incomplete, is not stored, and the host renders the batch again with worst-case queues.
 __device__ __forceinline__ bool batch_overflowed(const unsigned* __restrict__ counts, int maxDepth) {

@@ -133,6 +133,7 @@ struct EventPair {
 struct rtx_scene {
 	int device = 0;
 	int numCUs = 256;
+	long long mergeBlocks = 131072;  // frames of a multi-frame call share a batch up to this many 4x4-pixel blocks (RTX_MERGE_BLOCKS)
 	int traceRefill = TRACE_REFILL, traceChunk = TRACE_CHUNK, traceBlocksPerCU = 6, traceTriBatch = 24;  // tunables (RTX_TRACE_* env)
 	hipStream_t stream = nullptr;
 	hipStream_t ownStream = nullptr;
@@ -497,9 +498,12 @@ struct RenderTarget {
 	float* dTab;
 };
 
-// Renders the 4x4-pixel blocks [gBegin, gEnd) of this scene's tile share in as few pixel batches as the arena allows.
+// Renders the 4x4-pixel blocks [gBegin, gEnd) in as few pixel batches as the arena allows.  Blocks are numbered
+// over the frames of the call first (`frame` is the frame of block 0), then over the scene's tile share
+// (blocksPerFrame of them), so a batch may span frames.
 int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTarget& tg, long long gBegin, long long gEnd,
 				 bool useHistory) {
+	const long long blocksPerFrame = (long long)tile_slots(s) * BLOCKS_PER_TILE;
 	const int mode = tg.mode;
 	const int levels = (mode == 2) ? 0 : s->maxDepth;
 	double ratio[MAX_DEPTH + 2];
@@ -514,7 +518,11 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 	// per sample: A, B, C of those levels; two ping-pong ray sets and the set-aside list sized for the widest level
 	const double perSample = (mode == 2) ? (double)(NODE_BYTES + 2 * RAY_BYTES + 4) : sumRatio * NODE_BYTES + maxRatio * (2.0 * RAY_BYTES + 4.0);
 	const double fixedBytes = (double)(MAX_DEPTH + 8) * 4096 + (double)(levels + 1) * 1024.0 * NODE_BYTES + 1024.0 * (2.0 * RAY_BYTES + 4.0) + 65536.0;
-	const long long totalBlocks = gEnd - gBegin;
+	// Frames are merged into one batch up to about the samples of one 1080p frame (whole frames only; a share
+	// that is larger than that is rendered frame by frame as the arena allows): enough to fill the queues of a
+	// small tile share without multiplying the arena of a big one.
+	const long long mergeBlocks = std::max(blocksPerFrame, (s->mergeBlocks / blocksPerFrame) * blocksPerFrame);
+	const long long totalBlocks = std::min(gEnd - gBegin, mergeBlocks);
 
 	size_t freeB = 0, totalB = 0;
 	HIPCHK(hipMemGetInfo(&freeB, &totalB));
@@ -547,6 +555,8 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 		b.nSamples = (int)(nb * SAMPLES_PER_BLOCK);
 		b.tileFirst = s->tileFirst;
 		b.tileStride = s->tileStride;
+		b.blocksPerFrame = (int)blocksPerFrame;
+		b.frame0 = frame;
 		s->stats.chunks++;
 
 		// capacities of the levels of this batch
@@ -578,7 +588,7 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 		size_t ev;
 		rc = begin_event(s, 1, ev);
 		if (rc) return rc;
-		hipLaunchKernelGGL(k_raygen, dim3((b.nSamples + 255) / 256), dim3(256), 0, s->stream, d, b, frame, rayO[0], rayD[0]);
+		hipLaunchKernelGGL(k_raygen, dim3((b.nSamples + 255) / 256), dim3(256), 0, s->stream, d, b, rayO[0], rayD[0]);
 		HIPCHK(hipGetLastError());
 		rc = end_event(s, ev);
 		if (rc) return rc;
@@ -640,9 +650,18 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 								   (const int*)nullptr, (const float4*)nullptr, (unsigned)cap[lv + 1], (unsigned*)nullptr, nDev);
 			HIPCHK(hipGetLastError());
 		}
-		const int npix = b.nSamples / 4;
-		if (mode == 0)
-			hipLaunchKernelGGL(k_accumulate, dim3((npix + 255) / 256), dim3(256), 0, s->stream, d, b, A[0], s->dAccum, s->dCounts.p);
+		if (mode == 0) {
+			// one launch per frame the batch touches, in frame order
+			for (long long f = g0 / blocksPerFrame; f * blocksPerFrame < g0 + nb; ++f) {
+				const long long segBegin = std::max(g0, f * blocksPerFrame), segEnd = std::min(g0 + nb, (f + 1) * blocksPerFrame);
+				Batch seg = b;
+				seg.g0 = (int)segBegin;
+				seg.nSamples = (int)((segEnd - segBegin) * SAMPLES_PER_BLOCK);
+				const int npix = seg.nSamples / 4;
+				hipLaunchKernelGGL(k_accumulate, dim3((npix + 255) / 256), dim3(256), 0, s->stream, d, seg,
+								   (const float4*)(A[0] + (size_t)(segBegin - g0) * SAMPLES_PER_BLOCK), s->dAccum, s->dCounts.p);
+			}
+		}
 		else
 			hipLaunchKernelGGL(k_export_samples, dim3((b.nSamples + 255) / 256), dim3(256), 0, s->stream, d, b, A[0], tg.dOut, s->dCounts.p);
 		HIPCHK(hipGetLastError());
@@ -686,12 +705,20 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 	return harvest_events(s);
 }
 
-int render_batches(rtx_scene* s, uint32_t frame, int mode, int hitMode, float4* dOut, int* dIds, float* dTab) {
+// Frames frame .. frame + nFrames - 1 of the scene's tile share (nFrames > 1: accumulate mode only).
+int render_batches(rtx_scene* s, uint32_t frame, uint32_t nFrames, int mode, int hitMode, float4* dOut, int* dIds, float* dTab) {
 	const DevScene d = make_dev_scene(s);
-	const long long totalBlocks = (long long)tile_slots(s) * BLOCKS_PER_TILE;
-	if (totalBlocks == 0) return RTX_OK;
+	const long long blocksPerFrame = (long long)tile_slots(s) * BLOCKS_PER_TILE;
+	if (blocksPerFrame == 0) return RTX_OK;
 	const RenderTarget tg{mode, hitMode, dOut, dIds, dTab};
-	return render_range(s, d, frame, tg, 0, totalBlocks, s->haveHistory && !s->worstCaseQueues);
+	// block numbers stay inside int32: more frames than that go in several rounds
+	const uint32_t perRound = (uint32_t)std::max<long long>(1, std::min<long long>(nFrames, 0x7FFF0000ll / SAMPLES_PER_BLOCK / blocksPerFrame));
+	for (uint32_t f = 0; f < nFrames; f += perRound) {
+		const uint32_t nf = std::min(perRound, nFrames - f);
+		int rc = render_range(s, d, frame + f, tg, 0, blocksPerFrame * nf, s->haveHistory && !s->worstCaseQueues);
+		if (rc) return rc;
+	}
+	return RTX_OK;
 }
 
 int finish_stats(rtx_scene* s) {
@@ -743,6 +770,7 @@ RTX_API int rtx_scene_create(rtx_scene** out, int device) {
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->numCUs = prop.multiProcessorCount;
 	if (const char* e = std::getenv("RTX_TRACE_REFILL")) s->traceRefill = std::max(1, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_TRACE_CHUNK")) s->traceChunk = std::max(64, std::atoi(e));
+	if (const char* e = std::getenv("RTX_MERGE_BLOCKS")) s->mergeBlocks = std::max(1ll, std::atoll(e));
 	if (const char* e = std::getenv("RTX_TRACE_TRI_BATCH")) s->traceTriBatch = std::max(1, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_TRACE_BLOCKS_PER_CU")) s->traceBlocksPerCU = std::max(1, std::atoi(e));
 	if (const char* e = std::getenv("RTX_TRACE_BINARY")) s->forceBinary = std::atoi(e) != 0;
@@ -1114,13 +1142,11 @@ RTX_API int rtx_render_frames(rtx_scene* s, uint32_t first_frame, uint32_t n_fra
 	// the total-time event pair must survive the per-batch harvests: park it
 	EventPair total = s->events.back();
 	s->events.pop_back();
-	for (uint32_t f = 0; f < n_frames; ++f) {
-		rc = render_batches(s, first_frame + f, 0, 0, nullptr, nullptr, nullptr);
-		if (rc) {
-			(void)hipEventDestroy(total.a);
-			(void)hipEventDestroy(total.b);
-			return rc;
-		}
+	rc = render_batches(s, first_frame, n_frames, 0, 0, nullptr, nullptr, nullptr);
+	if (rc) {
+		(void)hipEventDestroy(total.a);
+		(void)hipEventDestroy(total.b);
+		return rc;
 	}
 	s->events.push_back(total);
 	rc = end_event(s, s->events.size() - 1);
@@ -1203,7 +1229,7 @@ RTX_API int rtx_primary_hits(rtx_scene* s, int mode, int32_t* tri_ids, float* t_
 		dTab.release();
 		return fail(RTX_ERR_DEVICE, hipGetErrorString(e));
 	}
-	rc = render_batches(s, 0, 2, mode, nullptr, dIds.p, t_alpha_beta ? dTab.p : nullptr);
+	rc = render_batches(s, 0, 1, 2, mode, nullptr, dIds.p, t_alpha_beta ? dTab.p : nullptr);
 	if (rc == RTX_OK) {
 		e = hipMemcpy(tri_ids, dIds.p, ns * sizeof(int), hipMemcpyDeviceToHost);
 		if (e == hipSuccess && t_alpha_beta) e = hipMemcpy(t_alpha_beta, dTab.p, ns * 3 * sizeof(float), hipMemcpyDeviceToHost);
@@ -1289,7 +1315,7 @@ RTX_API int rtx_sample_radiance(rtx_scene* s, uint32_t frame, float* host_out) {
 		dOut.release();
 		return fail(RTX_ERR_DEVICE, hipGetErrorString(e));
 	}
-	rc = render_batches(s, frame, 1, 0, dOut.p, nullptr, nullptr);
+	rc = render_batches(s, frame, 1, 1, 0, dOut.p, nullptr, nullptr);
 	if (rc == RTX_OK) {
 		e = hipMemcpy(host_out, dOut.p, ns * sizeof(float4), hipMemcpyDeviceToHost);
 		if (e != hipSuccess) rc = fail(RTX_ERR_DEVICE, hipGetErrorString(e));

@@ -220,8 +220,9 @@ def test_bunny_class_1080p_culled_equals_exhaustive(libs):
 
 def test_atrium_tiles_arena_and_determinism(libs):
     """Sponza-class scene at reduced resolution: (a) two tile shares rendered separately compose to
-    the single-share image, (b) a work arena 20x smaller (many pixel batches) gives the same image,
-    (c) a second run is identical, (d) a window of the image equals the CPU restatement."""
+    the single-share image, (b) a work arena 20x smaller (many pixel batches, cut anywhere inside the two frames)
+    gives the same image, (c) a second run is identical, (d) a window of the image equals the CPU restatement,
+    (e) one call over two frames (one merged batch) equals two calls of one frame."""
     sc = scenes.atrium_scene(width=320, height=200, max_depth=4)
     nodes = api.build_bvh(sc.tris)
     rt = api.RayTracer(0)
@@ -230,11 +231,17 @@ def test_atrium_tiles_arena_and_determinism(libs):
     rt.render(1, 2)
     full = rt.accum()
     st = rt.stats()
-    assert st["chunks"] == 2
+    assert st["chunks"] == 1          # the two small frames share one pixel batch
     # (c)
     rt.reset()
     rt.render(1, 2)
     assert_bits_equal(full, rt.accum(), "repeat")
+    # (e) frames merged into one batch accumulate in the order of frame-by-frame calls
+    rt.reset()
+    rt.render(1, 1)
+    rt.render(2, 1)
+    assert rt.stats()["chunks"] == 1
+    assert_bits_equal(full, rt.accum(), "frame by frame")
     # (b)
     rt.set_arena_bytes(int(320 * 200 * 4 * 3000 / 20))
     rt.reset()
