@@ -60,6 +60,7 @@ typedef struct rtx_stats {
 	uint64_t queue_retries;   /* pixel batches rendered again because a queue sized from earlier frames overflowed */
 	uint64_t rays_set_aside;  /* rays the wide traversal handed to the binary-tree kernel (rtx_render_frames only)  */
 	uint64_t rays_untraced;   /* last-level rays (counted in rays) whose value is zero hit or miss: not traversed   */
+	uint64_t rays_wave_traced;/* rays whose traversal proved long and was redone by a whole wave (rtx_render_frames only) */
 } rtx_stats;
 
 /* ------------------------------------------------------------------ device side (librtx_hip.so) */

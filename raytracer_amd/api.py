@@ -32,7 +32,7 @@ class Stats(C.Structure):
                 ("total_ms", C.c_double), ("trace_launches", _u32), ("chunks", _u32),
                 ("trace_ms_per_level", C.c_double * 16), ("wide_visits", C.c_uint64), ("leaf_fetches", C.c_uint64),
                 ("queue_retries", C.c_uint64), ("rays_set_aside", C.c_uint64),
-                ("rays_untraced", C.c_uint64)]
+                ("rays_untraced", C.c_uint64), ("rays_wave_traced", C.c_uint64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if not k.endswith("_per_level")}

@@ -17,6 +17,9 @@ constexpr int BLK = 4;              // a wave covers a BLK x BLK pixel block x 4
 constexpr int BLOCKS_PER_TILE = (TILE / BLK) * (TILE / BLK);
 constexpr int SAMPLES_PER_BLOCK = BLK * BLK * 4;  // 64 = one wave
 constexpr int TRACE_THREADS = 256;
+// Counter block of a recursion level (unsigned words, zeroed at the start of a pixel batch): 0 queue length,
+// 1 dead slots, 2 shaded hits, 3 texel fetches, 4 overflow flag, 5-9 cursors and list lengths of the traversal.
+constexpr int CNT_STRIDE = 16;
 
 enum NodeKind : int { KIND_LEAF = 0, KIND_METAL = 1, KIND_TRANSP = 2, KIND_DIEL = 3 };
 // a node's tag word: kind in bits 0-3, flags in bits 4-5, the texel's three bytes in bits 8-31
@@ -52,7 +55,7 @@ struct DevScene {
 // Bits of DevScene::fault.  An index is checked wherever it comes out of a queue record and is about to address
 // scene data: a record nobody wrote must end in an error code, never in an access outside the arrays.
 constexpr unsigned FAULT_HIT_RANK = 1u, FAULT_TEX_ID = 2u, FAULT_CHILD_SLOT = 4u, FAULT_NODE = 8u, FAULT_LEAF = 16u,
-				   FAULT_STACK = 32u;
+				   FAULT_STACK = 32u, FAULT_LONG_ROUNDS = 64u;
 
 // ------------------------------------------------------------------------------------------------
 // Small device helpers.  dot4 is Eigen's reduction order with the (zero) w lane kept as "+ 0.0f".

@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void k_gather(DevScene sc, int n, float4* __re
 // result is then incomplete, is not stored, and the host renders the batch again with worst-case queues.
 __device__ __forceinline__ bool batch_overflowed(const unsigned* __restrict__ counts, int maxDepth) {
 	unsigned f = 0;
-	for (int lv = 1; lv <= maxDepth + 1; ++lv) f |= counts[lv * 8 + 4];
+	for (int lv = 1; lv <= maxDepth + 1; ++lv) f |= counts[lv * CNT_STRIDE + 4];
 	return f != 0;
 }
 

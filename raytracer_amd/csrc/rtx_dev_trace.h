@@ -351,7 +351,8 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 															   int n, unsigned long long* __restrict__ stats,
 															   unsigned* __restrict__ work, int* __restrict__ unsafeList,
 															   unsigned* __restrict__ unsafeCount, int refill, int chunk,
-															   int triBatch, const unsigned* __restrict__ nDev) {
+															   int triBatch, const unsigned* __restrict__ nDev,
+															   int* __restrict__ longList, unsigned* __restrict__ longCount, int longVisits) {
 	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
 	// A short queue is cut into smaller chunks, so that every wave of the grid has about three to take: with
 	// chunks of the full size a queue of a million rays would occupy two waves in three and the launch would
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 	best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
 	bool found = false, busy = false;
 	int pend0 = -1, pend1 = -1;
+	int visitsLeft = 0;  // nodes this lane's ray may still visit here before it moves to k_trace_long
 
 	for (;;) {
 		const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
@@ -451,6 +453,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 							cur = 0;
 							pend0 = pend1 = -1;
 							busy = true;
+							visitsLeft = longVisits;
 						}
 					}
 				}
@@ -543,6 +546,15 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 				sp = 0;
 			}
 #endif
+			if (cur >= 0 && --visitsLeft < 0) {
+				// A launch lasts as long as its longest ray, and one lane walks one node after the other.  A ray
+				// that has used up its allowance starts over in k_trace_long, where a whole wave works on it.
+				longList[atomicAdd(longCount, 1u)] = j;
+				busy = false;
+				cur = -1;
+				sp = 0;
+				pend0 = -1;
+			}
 			if (cur >= 0) {
 				const float4* W = sc.wide + (size_t)cur * 4;
 				float4 w0 = W[0], w1 = W[1], w2 = W[2], w3 = W[3];
@@ -659,6 +671,181 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 		if (lane == 0) {
 			atomicAdd(&stats[8], (unsigned long long)overflows);
 		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// One wave per ray, for the few rays whose traversal is long (a ray skimming a finely tessellated surface
+// visits hundreds of nodes; walked by one lane, it alone decides how long its level's launch lasts).
+//
+// Same tree, same tests, same answer as k_trace_wide; only the schedule differs.  The wave keeps the ray's open
+// nodes in a stack in LDS and takes the top 16 at a time: lane 4s+c tests child c of node s.  Children that are
+// entered go back on the stack, leaves into a list; once the list holds 64 leaves (or the stack is empty) every
+// lane tests one leaf with the exact box predicate and the exact Triangle::hit, and the wave keeps the minimum
+// of (t, rank) -- the reference's "smallest t, first candidate on ties" -- so the order of the visits cannot
+// change the result.  The best t so far is uniform over the wave and culls as in k_trace_wide.
+// A ray whose stack would overflow, or that meets the NaN-in-lane-0 case at a leaf, goes on to the set-aside
+// list of the binary-tree kernel, which runs after this one.
+constexpr int LONG_STACK = 1024;     // open nodes per ray
+constexpr int LONG_LEAVES = 128;     // >= 64 (the trigger) + 64 (one step's yield)
+
+template <bool ANYHIT, bool STATS>
+__global__ __launch_bounds__(TRACE_THREADS) void k_trace_long(DevScene sc, const float4* __restrict__ rayO,
+															  const float4* __restrict__ rayD, float4* __restrict__ hits,
+															  const int* __restrict__ list, const unsigned* __restrict__ listCount,
+															  int* __restrict__ unsafeList,
+															  unsigned* __restrict__ unsafeCount, unsigned long long* __restrict__ stats) {
+	__shared__ int sStack[TRACE_THREADS / 64][LONG_STACK];
+	__shared__ int sLeaf[TRACE_THREADS / 64][LONG_LEAVES];
+	const unsigned lane = threadIdx.x & 63u;
+	const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+	int* stk = sStack[w];
+	int* lf = sLeaf[w];
+	const unsigned count = *listCount;
+	unsigned nodeVisits = 0, leafFetches = 0, boxTests = 0, triTests = 0;  // wave-level, kept uniform
+	// Everything a wave does here is uniform over its lanes, and the code keeps it visibly so: no statement is
+	// guarded by "lane == 0" (all lanes store the same value to the same place instead).  Lanes that skip such a
+	// guard may otherwise be scheduled ahead of lane 0 into the next ballot or shuffle, which then sees half a wave.
+	const unsigned nWaves = gridDim.x * (TRACE_THREADS / 64);
+	for (unsigned idx = blockIdx.x * (TRACE_THREADS / 64) + (unsigned)w; idx < count; idx += nWaves) {
+		const int j = list[idx];
+		const float4 O = rayO[j], D = rayD[j];
+		// the ray was being walked by k_trace_wide, so its reciprocals are finite or infinite, never huge
+		RaySlab r;
+		r.ox = O.x; r.oy = O.y; r.oz = O.z;
+		const float dx = D.x, dy = D.y, dz = D.z;
+		r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
+		r.nx = (__float_as_uint(r.ix) >> 31) != 0;
+		r.ny = (__float_as_uint(r.iy) >> 31) != 0;
+		r.nz = (__float_as_uint(r.iz) >> 31) != 0;
+		const float aix = fabsf(r.ix), aiy = fabsf(r.iy), aiz = fabsf(r.iz);
+		const float wix = aix > FLT_MAX ? copysignf(WIDE_MAX_INV, r.ix) : r.ix;
+		const float wiy = aiy > FLT_MAX ? copysignf(WIDE_MAX_INV, r.iy) : r.iy;
+		const float wiz = aiz > FLT_MAX ? copysignf(WIDE_MAX_INV, r.iz) : r.iz;
+		const float scale = fmaxf(fmaxf(sc.sceneAbsMax, fabsf(r.ox)), fmaxf(fabsf(r.oy), fabsf(r.oz)));
+		const float eps = scale * 6.103515625e-05f;
+		r.mx = eps * fabsf(wix); r.my = eps * fabsf(wiy); r.mz = eps * fabsf(wiz);
+
+		HitState best;  // uniform over the wave
+		best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
+		bool found = false, aside = false;
+		int nStk = 1, nLeaf = 0;  // uniform
+		stk[0] = 0;
+		__builtin_amdgcn_wave_barrier();
+		const int slot = (int)(lane >> 2), child = (int)(lane & 3u);
+		// every round takes at least one node or one leaf off the lists and nothing is visited twice
+		const unsigned maxRounds = (unsigned)sc.nWide + (unsigned)sc.nTris + 2u;
+		unsigned rounds = 0;
+		while (nStk > 0 || nLeaf > 0) {
+			if (++rounds > maxRounds) {
+				atomicOr(sc.fault, FAULT_LONG_ROUNDS);  // the tree is not a tree
+				aside = true;
+				break;
+			}
+			if (nLeaf >= 64 || nStk == 0) {
+				// leaf phase: the newest (at most 64) leaves, one per lane
+				const int take = min(nLeaf, 64);
+				nLeaf -= take;
+				unsigned long long key = ~0ull;
+				HitState cand = best;
+				bool nanX = false;
+				if ((int)lane < take) {
+					const int rank = lf[nLeaf + (int)lane];
+					const float4* T = sc.triHit + (size_t)rank * 4;
+					const float4 q0 = T[0], q1 = T[1], q2 = T[2];
+					const float v0x = q0.w, v0y = q1.x, v0z = q1.y, v1x = q1.z, v1y = q1.w, v1z = q2.x, v2x = q2.y, v2y = q2.z, v2z = q2.w;
+					const float lx = fminf(fminf(v0x, v1x), v2x), hx = fmaxf(fmaxf(v0x, v1x), v2x);
+					const float ly = fminf(fminf(v0y, v1y), v2y), hy = fmaxf(fmaxf(v0y, v1y), v2y);
+					const float lz = fminf(fminf(v0z, v1z), v2z), hz = fmaxf(fmaxf(v0z, v1z), v2z);
+					const float t0x = (lx - r.ox) * r.ix, t1x = (hx - r.ox) * r.ix;
+					const float t0y = (ly - r.oy) * r.iy, t1y = (hy - r.oy) * r.iy;
+					const float t0z = (lz - r.oz) * r.iz, t1z = (hz - r.oz) * r.iz;
+					const float tmin = fmaxf(fmaxf(r.nx ? t1x : t0x, r.ny ? t1y : t0y), r.nz ? t1z : t0z);
+					const float tmax = fminf(fminf(r.nx ? t0x : t1x, r.ny ? t0y : t1y), r.nz ? t0z : t1z);
+					nanX = t0x != t0x || t1x != t1x;
+					if (!nanX && !(tmax < tmin)) {
+						if (tri_test_vals(q0.x, q0.y, q0.z, v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z, rank, r.ox, r.oy, r.oz,
+										  dx, dy, dz, cand))
+							key = ((unsigned long long)__float_as_uint(cand.t) << 32) | (unsigned)cand.rank;
+					}
+				}
+				if (STATS) { leafFetches += take; boxTests += take; triTests += take; }
+				if (__builtin_amdgcn_ballot_w64(nanX) != 0ull) {
+					// only the reference's own tree can tell whether that leaf is reached (see k_trace_wide)
+					aside = true;
+					break;
+				}
+				// minimum of (t, rank) over the wave; a triangle is in the list at most once, so the winner is unique
+				unsigned long long m = key;
+				for (int off = 32; off > 0; off >>= 1) {
+					const unsigned long long o = __shfl_xor(m, off, 64);
+					m = o < m ? o : m;
+				}
+				if (m != ~0ull) {
+					const int win = __ffsll((long long)__builtin_amdgcn_ballot_w64(key == m)) - 1;
+					best.t = __shfl(cand.t, win, 64);
+					best.alpha = __shfl(cand.alpha, win, 64);
+					best.beta = __shfl(cand.beta, win, 64);
+					best.rank = __shfl(cand.rank, win, 64);
+					found = true;
+					if (ANYHIT) break;
+				}
+				continue;
+			}
+			// node phase: the newest (at most 16) open nodes, four lanes each
+			const int take = min(nStk, 16);
+			nStk -= take;
+			int code = 0;
+			bool h = false;
+			if (slot < take) {
+				const int node = stk[nStk + slot];
+				const float4* W = sc.wide + (size_t)node * 4;
+				const float4 w0 = W[0], w1 = W[1], w2 = W[2], w3 = W[3];
+				const float Sx = w0.w * wix, Sy = w3.z * wiy, Sz = w3.w * wiz;
+				const float Ax = (w0.x - r.ox) * wix, Ay = (w0.y - r.oy) * wiy, Az = (w0.z - r.oz) * wiz;
+				const float Anx = Ax - r.mx, Any = Ay - r.my, Anz = Az - r.mz;
+				const float Afx = Ax + r.mx, Afy = Ay + r.my, Afz = Az + r.mz;
+				const unsigned lox = __float_as_uint(w1.x), hix = __float_as_uint(w1.y), loy = __float_as_uint(w1.z),
+							   hiy = __float_as_uint(w1.w), loz = __float_as_uint(w2.x), hiz = __float_as_uint(w2.y);
+				const unsigned nxd = r.nx ? hix : lox, fxd = r.nx ? lox : hix;
+				const unsigned nyd = r.ny ? hiy : loy, fyd = r.ny ? loy : hiy;
+				const unsigned nzd = r.nz ? hiz : loz, fzd = r.nz ? loz : hiz;
+				const int sh = child * 8;
+				float e = fmaxf(fmaxf(__fmaf_rn((float)((nxd >> sh) & 0xFFu), Sx, Anx), __fmaf_rn((float)((nyd >> sh) & 0xFFu), Sy, Any)),
+								__fmaf_rn((float)((nzd >> sh) & 0xFFu), Sz, Anz));
+				const float x = fminf(fminf(__fmaf_rn((float)((fxd >> sh) & 0xFFu), Sx, Afx), __fmaf_rn((float)((fyd >> sh) & 0xFFu), Sy, Afy)),
+									  __fmaf_rn((float)((fzd >> sh) & 0xFFu), Sz, Afz));
+				e = fmaxf(e, 0.001f);
+				code = child == 0 ? __float_as_int(w2.z) : child == 1 ? __float_as_int(w2.w) : child == 2 ? __float_as_int(w3.x) : __float_as_int(w3.y);
+				h = (code != 0) & !(x < e) & !(e > best.t);
+			}
+			if (STATS) { nodeVisits += take; boxTests += 4 * take; }
+			const unsigned long long mNode = __builtin_amdgcn_ballot_w64(h && code > 0);
+			const unsigned long long mLeaf = __builtin_amdgcn_ballot_w64(h && code < 0);
+			if (nStk + __popcll(mNode) > LONG_STACK) {
+				aside = true;
+				break;
+			}
+			if (h && code > 0) stk[nStk + __popcll(mNode & below)] = code;
+			if (h && code < 0) lf[nLeaf + __popcll(mLeaf & below)] = ~code;
+			nStk += __popcll(mNode);
+			nLeaf += __popcll(mLeaf);
+			__builtin_amdgcn_wave_barrier();  // the next round's lanes read what other lanes have just written
+		}
+		if (aside) {
+			// one list slot for the wave: lane 0 adds 1 and the others 0, so what lane 0 receives is the slot
+			const unsigned got = atomicAdd(unsafeCount, lane == 0 ? 1u : 0u);
+			unsafeList[(unsigned)__builtin_amdgcn_readfirstlane((int)got)] = j;
+		}
+		else
+			put_hit<ANYHIT>(hits, j, found ? (ANYHIT ? 0 : best.rank) : -1, best.t, best.alpha, best.beta);
+	}
+	if (STATS && lane == 0) {
+		atomicAdd(&stats[0], (unsigned long long)boxTests);
+		atomicAdd(&stats[1], (unsigned long long)triTests);
+		atomicAdd(&stats[4], (unsigned long long)nodeVisits);
+		atomicAdd(&stats[5], (unsigned long long)leafFetches);
 	}
 }
 

@@ -40,6 +40,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <chrono>
@@ -133,6 +134,7 @@ struct EventPair {
 struct rtx_scene {
 	int device = 0;
 	int numCUs = 256;
+	int longVisits = 64;             // nodes one lane walks for a ray before a whole wave takes the ray over (RTX_LONG_VISITS, 0 = never)
 	long long mergeBlocks = 131072;  // frames of a multi-frame call share a batch up to this many 4x4-pixel blocks (RTX_MERGE_BLOCKS)
 	int traceRefill = TRACE_REFILL, traceChunk = TRACE_CHUNK, traceBlocksPerCU = 6, traceTriBatch = 24;  // tunables (RTX_TRACE_* env)
 	hipStream_t stream = nullptr;
@@ -205,7 +207,6 @@ struct rtx_scene {
 namespace {
 
 constexpr int MAX_DEPTH = 15;
-constexpr int CNT_STRIDE = 8;   // per level: 0 queue length, 1 dead, 2 shaded, 3 texel fetches, 4 overflow flag, 5-7 trace cursors
 constexpr int FAULT_WORD = (MAX_DEPTH + 2) * CNT_STRIDE;  // behind the level blocks: the kernels' consistency checks (DevScene::fault)
 constexpr int COUNT_WORDS = FAULT_WORD + CNT_STRIDE;
 
@@ -372,6 +373,7 @@ int harvest_events(rtx_scene* s) {
 constexpr int WORK_SLOT = 5;     // queue cursor of the wide traversal
 constexpr int UNSAFE_SLOT = 6;   // number of rays set aside for the binary-tree kernel
 constexpr int WORK2_SLOT = 7;    // queue cursor of the binary-tree kernel
+constexpr int LONG_SLOT = 8;     // number of rays handed to the wave-per-ray kernel
 
 // The binary-tree kernel (every ancestor box evaluated as the reference does).  With a list it
 // traces list[0 .. *listCount); the count lives on the device, so the grid is a fixed small one.
@@ -405,7 +407,7 @@ int launch_exact_t(rtx_scene* s, const DevScene& d, const float4* ro, const floa
 
 template <bool ANYHIT>
 int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float4* rd, float4* hits, int n, unsigned* work,
-				  int* unsafeList, unsigned* unsafeCount, const unsigned* nDev) {
+				  int* unsafeList, unsigned* unsafeCount, const unsigned* nDev, int* longList, unsigned* longCount) {
 	const int wanted = nDev ? s->numCUs * s->traceBlocksPerCU : (n + TRACE_THREADS - 1) / TRACE_THREADS;
 	dim3 grid(std::min(wanted, s->numCUs * s->traceBlocksPerCU)), block(TRACE_THREADS);
 	// The stack is no deeper than wideStackCap entries however deep the tree: a ray that would need more
@@ -415,7 +417,8 @@ int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float
 	unsigned long long* stats = s->dStats.p;
 #define RTX_LAUNCH(STK, ST)                                                                                              \
 	hipLaunchKernelGGL((k_trace_wide<STK, ANYHIT, ST>), grid, block, 0, s->stream, d, ro, rd, hits, n, stats, work,      \
-					   unsafeList, unsafeCount, s->traceRefill, s->traceChunk, s->traceTriBatch, nDev)
+					   unsafeList, unsafeCount, s->traceRefill, s->traceChunk, s->traceTriBatch, nDev, longList, longCount, \
+					   s->longVisits)
 	if (need <= 16) {
 		if (st) RTX_LAUNCH(16, true); else RTX_LAUNCH(16, false);
 	}
@@ -427,8 +430,26 @@ int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float
 	return RTX_OK;
 }
 
-// One queue of rays -> hit records.  `cnt` is the level's zeroed counter block, `unsafeList` room for n ints.
-// Production: wide traversal, then the binary-tree kernel over the rays the wide one set aside.
+// The wave-per-ray kernel over the rays the wide traversal found too long for one lane; the count lives on the
+// device, so the grid is a fixed small one.
+template <bool ANYHIT>
+int launch_long_t(rtx_scene* s, const DevScene& d, const float4* ro, const float4* rd, float4* hits, const int* longList,
+				  const unsigned* longCount, int* unsafeList, unsigned* unsafeCount) {
+	dim3 grid(std::max(1, s->numCUs * 2)), block(TRACE_THREADS);
+	if (s->instrumented)
+		hipLaunchKernelGGL((k_trace_long<ANYHIT, true>), grid, block, 0, s->stream, d, ro, rd, hits, longList, longCount, unsafeList,
+						   unsafeCount, s->dStats.p);
+	else
+		hipLaunchKernelGGL((k_trace_long<ANYHIT, false>), grid, block, 0, s->stream, d, ro, rd, hits, longList, longCount, unsafeList,
+						   unsafeCount, s->dStats.p);
+	HIPCHK(hipGetLastError());
+	return RTX_OK;
+}
+
+// One queue of rays -> hit records.  `cnt` is the level's zeroed counter block, `unsafeList` room for 2n ints (the
+// set-aside list in the first n, the list of long rays behind it).
+// Production: wide traversal, then the wave-per-ray kernel over the rays that proved long, then the binary-tree
+// kernel over the rays either of them set aside.
 // Exhaustive: the binary-tree kernel without culling over the whole queue.
 int launch_trace(rtx_scene* s, const DevScene& d, bool anyhit, bool exhaustive, const float4* ro, const float4* rd,
 				 float4* hits, int n, unsigned* cnt, int* unsafeList, int level = 0, const unsigned* nDev = nullptr) {
@@ -442,12 +463,16 @@ int launch_trace(rtx_scene* s, const DevScene& d, bool anyhit, bool exhaustive, 
 		rc = anyhit ? launch_exact_t<true, false>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, nullptr, nullptr, nDev)
 					: launch_exact_t<false, false>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, nullptr, nullptr, nDev);
 	else if (anyhit) {
-		rc = launch_wide_t<true>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, unsafeList, cnt + UNSAFE_SLOT, nDev);
+		rc = launch_wide_t<true>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, unsafeList, cnt + UNSAFE_SLOT, nDev, unsafeList + n, cnt + LONG_SLOT);
+		if (rc == RTX_OK && s->longVisits != INT_MAX && !std::getenv("RTX_LONG_SKIP"))
+			rc = launch_long_t<true>(s, d, ro, rd, hits, unsafeList + n, cnt + LONG_SLOT, unsafeList, cnt + UNSAFE_SLOT);
 		if (rc == RTX_OK)
 			rc = launch_exact_t<true, false>(s, d, ro, rd, hits, n, cnt + WORK2_SLOT, unsafeList, cnt + UNSAFE_SLOT, nullptr);
 	}
 	else {
-		rc = launch_wide_t<false>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, unsafeList, cnt + UNSAFE_SLOT, nDev);
+		rc = launch_wide_t<false>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, unsafeList, cnt + UNSAFE_SLOT, nDev, unsafeList + n, cnt + LONG_SLOT);
+		if (rc == RTX_OK && s->longVisits != INT_MAX && !std::getenv("RTX_LONG_SKIP"))
+			rc = launch_long_t<false>(s, d, ro, rd, hits, unsafeList + n, cnt + LONG_SLOT, unsafeList, cnt + UNSAFE_SLOT);
 		if (rc == RTX_OK)
 			rc = launch_exact_t<false, false>(s, d, ro, rd, hits, n, cnt + WORK2_SLOT, unsafeList, cnt + UNSAFE_SLOT, nullptr);
 	}
@@ -515,9 +540,9 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 		if (lv < levels) sumRatio += ratio[lv];
 		maxRatio = std::max(maxRatio, ratio[lv]);
 	}
-	// per sample: A, B, C of those levels; two ping-pong ray sets and the set-aside list sized for the widest level
-	const double perSample = (mode == 2) ? (double)(NODE_BYTES + 2 * RAY_BYTES + 4) : sumRatio * NODE_BYTES + maxRatio * (2.0 * RAY_BYTES + 4.0);
-	const double fixedBytes = (double)(MAX_DEPTH + 8) * 4096 + (double)(levels + 1) * 1024.0 * NODE_BYTES + 1024.0 * (2.0 * RAY_BYTES + 4.0) + 65536.0;
+	// per sample: A and B of those levels; two ping-pong ray sets and the two ray lists (set aside, long) sized for the widest level
+	const double perSample = (mode == 2) ? (double)(NODE_BYTES + 2 * RAY_BYTES + 8) : sumRatio * NODE_BYTES + maxRatio * (2.0 * RAY_BYTES + 8.0);
+	const double fixedBytes = (double)(MAX_DEPTH + 8) * 4096 + (double)(levels + 1) * 1024.0 * NODE_BYTES + 1024.0 * (2.0 * RAY_BYTES + 8.0) + 65536.0;
 	// Frames are merged into one batch up to about the samples of one 1080p frame (whole frames only; a share
 	// that is larger than that is rendered frame by frame as the arena allows): enough to fill the queues of a
 	// small tile share without multiplying the arena of a big one.
@@ -575,7 +600,7 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 
 		// arena carve-up: transient ray sets at the top, node arrays bump-allocated from the bottom
 		const size_t setBytes = ((widestCap * 16 + 255) & ~(size_t)255);
-		const size_t listBytes = ((widestCap * 4 + 255) & ~(size_t)255);
+		const size_t listBytes = ((widestCap * 8 + 255) & ~(size_t)255);  // set-aside list + list of long rays
 		Bump bump{s->arena.p, s->arena.n, 0, s->arena.n};
 		if (6 * setBytes + listBytes > bump.cap) return fail(RTX_ERR_MEMORY, "work arena too small for one pixel block");
 		bump.hi = bump.cap - 6 * setBytes - listBytes;
@@ -698,6 +723,7 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 			else s->stats.shaded_hits += hc[2];
 			s->stats.texture_fetches += hc[3];
 			s->stats.rays_set_aside += s->hCounts[(size_t)lv * CNT_STRIDE + UNSAFE_SLOT];
+			s->stats.rays_wave_traced += s->hCounts[(size_t)lv * CNT_STRIDE + LONG_SLOT];
 			n = hc[0];
 		}
 	}
@@ -770,6 +796,7 @@ RTX_API int rtx_scene_create(rtx_scene** out, int device) {
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->numCUs = prop.multiProcessorCount;
 	if (const char* e = std::getenv("RTX_TRACE_REFILL")) s->traceRefill = std::max(1, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_TRACE_CHUNK")) s->traceChunk = std::max(64, std::atoi(e));
+	if (const char* e = std::getenv("RTX_LONG_VISITS")) s->longVisits = std::atoi(e) > 0 ? std::atoi(e) : INT_MAX;
 	if (const char* e = std::getenv("RTX_MERGE_BLOCKS")) s->mergeBlocks = std::max(1ll, std::atoll(e));
 	if (const char* e = std::getenv("RTX_TRACE_TRI_BATCH")) s->traceTriBatch = std::max(1, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_TRACE_BLOCKS_PER_CU")) s->traceBlocksPerCU = std::max(1, std::atoi(e));
@@ -1269,7 +1296,7 @@ RTX_API int rtx_trace_rays(rtx_scene* s, int mode, uint32_t n, const float* orig
 	DevBuf<int> dIds, dList;
 	DevBuf<float> dTab;
 	hipError_t e = dO.alloc(n);
-	if (e == hipSuccess) e = dList.alloc(n);
+	if (e == hipSuccess) e = dList.alloc((size_t)n * 2);
 	if (e == hipSuccess) e = dD.alloc(n);
 	if (e == hipSuccess) e = dH.alloc(n);
 	if (e == hipSuccess) e = dIds.alloc(n);

@@ -355,6 +355,89 @@ def test_trees_the_wide_kernel_cannot_use_and_short_stacks(libs, monkeypatch):
     assert short.stats()["rays_set_aside"] >= ref.stats()["rays_set_aside"]
 
 
+@pytest.mark.parametrize("visits", ["2", "9"])
+def test_long_rays_taken_over_by_a_whole_wave(libs, monkeypatch, visits):
+    """A ray that has visited its allowance of nodes in the one-ray-per-lane kernel starts over in the kernel that
+    gives it a whole wave.  With an allowance of a few nodes nearly every ray takes that route: primary hits must
+    equal the exhaustive traversal and the restatement, the accumulator the restatement's, bit for bit, in a scene
+    with every material (closest-hit levels) and a last level (any-hit)."""
+    sc = scenes.mixed_scene(seed=5, width=96, height=64, max_depth=3, n_diff=2, n_spec=1)
+    nodes = api.build_bvh(sc.tris)
+    monkeypatch.setenv("RTX_LONG_VISITS", visits)
+    rt = api.RayTracer(0)
+    monkeypatch.delenv("RTX_LONG_VISITS")
+    rt.load_scene(sc, nodes)
+    O = binding.Oracle()
+    load_into(O, sc, build=False)
+    O.set_nodes(nodes)
+    ids_o, tab_o = O.primary_hits()
+    ids0, tab0 = rt.primary_hits(0)
+    ids1, tab1 = rt.primary_hits(1)
+    assert np.array_equal(ids0, ids1) and np.array_equal(ids0, ids_o)
+    assert_bits_equal(tab0[ids0 >= 0], tab_o[ids0 >= 0], "t/alpha/beta")
+    rt.reset()
+    rt.render(1, 2)
+    st = rt.stats()
+    assert st["rays_wave_traced"] > st["rays"] // 4, st
+    want = np.zeros((sc.height, sc.width, 4), np.float32)
+    for f in (1, 2):
+        O.render_rows(f, want, nthreads=8)
+    assert_bits_equal(want[..., :3], rt.accum()[..., :3], "accumulator")
+    assert st["rays"] == O.ray_count()
+    # degenerate and axis-parallel rays through the same route
+    rng = np.random.default_rng(3)
+    m = 3000
+    o = rng.uniform(-3, 3, (m, 3)).astype(np.float32)
+    d = rng.normal(0, 1, (m, 3)).astype(np.float32)
+    d[:300, 0] = 0
+    d[300:600, 1] = 0
+    d[600:900, 2] = 0
+    d[900:1000, :2] = 0
+    i0, t0 = rt.trace_rays(o, d, 0)
+    i1, t1 = rt.trace_rays(o, d, 1)
+    assert np.array_equal(i0, i1)
+    assert_bits_equal(t0[i0 >= 0], t1[i0 >= 0], "arbitrary rays")
+
+
+def test_multi_million_triangle_mesh_depth_8(libs):
+    """The stress configuration in small: a 2-million-triangle displaced mesh at depth 8 (finely tessellated, so
+    grazing rays visit hundreds of nodes and the wave-per-ray kernel gets real work).  Culled traversal ==
+    exhaustive traversal on every primary sample, a band of rows of the accumulator == the restatement, and the
+    image does not depend on where a ray was traced (allowance 16 instead of the default)."""
+    sc = scenes.heightfield_scene(n_tris=2000000, width=480, height=270)
+    sc.max_depth = 8
+    sc.n_diff = 1
+    sc.n_spec = 1
+    nodes = api.build_bvh(sc.tris)
+    rt = api.RayTracer(0)
+    rt.load_scene(sc, nodes)
+    ids0, tab0 = rt.primary_hits(0)
+    ids1, tab1 = rt.primary_hits(1)
+    assert np.array_equal(ids0, ids1)
+    assert_bits_equal(tab0[ids0 >= 0], tab1[ids0 >= 0], "t/alpha/beta")
+    rt.reset()
+    rt.render(1, 1)
+    st = rt.stats()
+    full = rt.accum()
+    assert st["rays_wave_traced"] > 0 and st["rays"] == sum(st["rays_per_level"])
+    O = binding.Oracle()
+    load_into(O, sc, build=False)
+    O.set_nodes(nodes)
+    acc_o = np.zeros((sc.height, sc.width, 4), np.float32)
+    O.render_rows(1, acc_o, row0=150, row1=156, nthreads=16)
+    assert_bits_equal(acc_o[150:156, :, :3], full[150:156, :, :3], "rows 150..155 vs CPU")
+    os.environ["RTX_LONG_VISITS"] = "16"
+    try:
+        rt2 = api.RayTracer(0)
+    finally:
+        del os.environ["RTX_LONG_VISITS"]
+    rt2.load_scene(sc, nodes)
+    rt2.reset()
+    rt2.render(1, 1)
+    assert rt2.stats()["rays_wave_traced"] > st["rays_wave_traced"]
+    assert_bits_equal(full, rt2.accum(), "allowance 16")
+
+
 def test_queue_history_overflow_is_rendered_again(libs):
     """Queues are sized from the ray populations of earlier frames.  History taken from one tile of sky makes
     the queues of the full image far too small: the device notices, stores nothing of such a batch, and the
