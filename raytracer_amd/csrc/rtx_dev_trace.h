@@ -352,8 +352,12 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 															   unsigned* __restrict__ work, int* __restrict__ unsafeList,
 															   unsigned* __restrict__ unsafeCount, int refill, int chunk,
 															   int triBatch, const unsigned* __restrict__ nDev,
-															   int* __restrict__ longList, unsigned* __restrict__ longCount, int longVisits) {
+															   int* __restrict__ longList, unsigned* __restrict__ longCount, int longVisits,
+															   int smallQueue) {
 	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
+	// A queue of a few thousand rays cannot fill the chip with one ray per lane; its launch would last as long as
+	// its longest ray walked by a single lane.  All its rays go to k_trace_long, a wave each, at once.
+	if (n <= smallQueue) longVisits = 0;
 	// A short queue is cut into smaller chunks, so that every wave of the grid has about three to take: with
 	// chunks of the full size a queue of a million rays would occupy two waves in three and the launch would
 	// last as long as one wave needs for its whole chunk.

@@ -134,6 +134,8 @@ struct EventPair {
 struct rtx_scene {
 	int device = 0;
 	int numCUs = 256;
+	int longBlocksPerCU = 8;         // grid of k_trace_long (RTX_LONG_BLOCKS)
+	int smallQueueFactor = 16;       // queues of up to this many rays per wave of k_trace_long go there entirely (RTX_SMALL_QUEUE)
 	int longVisits = 64;             // nodes one lane walks for a ray before a whole wave takes the ray over (RTX_LONG_VISITS, 0 = never)
 	long long mergeBlocks = 131072;  // frames of a multi-frame call share a batch up to this many 4x4-pixel blocks (RTX_MERGE_BLOCKS)
 	int traceRefill = TRACE_REFILL, traceChunk = TRACE_CHUNK, traceBlocksPerCU = 6, traceTriBatch = 24;  // tunables (RTX_TRACE_* env)
@@ -418,7 +420,7 @@ int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float
 #define RTX_LAUNCH(STK, ST)                                                                                              \
 	hipLaunchKernelGGL((k_trace_wide<STK, ANYHIT, ST>), grid, block, 0, s->stream, d, ro, rd, hits, n, stats, work,      \
 					   unsafeList, unsafeCount, s->traceRefill, s->traceChunk, s->traceTriBatch, nDev, longList, longCount, \
-					   s->longVisits)
+					   s->longVisits, s->longVisits == INT_MAX ? -1 : s->numCUs * s->longBlocksPerCU * (TRACE_THREADS / 64) * s->smallQueueFactor)
 	if (need <= 16) {
 		if (st) RTX_LAUNCH(16, true); else RTX_LAUNCH(16, false);
 	}
@@ -435,7 +437,7 @@ int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float
 template <bool ANYHIT>
 int launch_long_t(rtx_scene* s, const DevScene& d, const float4* ro, const float4* rd, float4* hits, const int* longList,
 				  const unsigned* longCount, int* unsafeList, unsigned* unsafeCount) {
-	dim3 grid(std::max(1, s->numCUs * 2)), block(TRACE_THREADS);
+	dim3 grid(std::max(1, s->numCUs * s->longBlocksPerCU)), block(TRACE_THREADS);
 	if (s->instrumented)
 		hipLaunchKernelGGL((k_trace_long<ANYHIT, true>), grid, block, 0, s->stream, d, ro, rd, hits, longList, longCount, unsafeList,
 						   unsafeCount, s->dStats.p);
@@ -796,6 +798,8 @@ RTX_API int rtx_scene_create(rtx_scene** out, int device) {
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->numCUs = prop.multiProcessorCount;
 	if (const char* e = std::getenv("RTX_TRACE_REFILL")) s->traceRefill = std::max(1, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_TRACE_CHUNK")) s->traceChunk = std::max(64, std::atoi(e));
+	if (const char* e = std::getenv("RTX_LONG_BLOCKS")) s->longBlocksPerCU = std::max(1, std::min(8, std::atoi(e)));
+	if (const char* e = std::getenv("RTX_SMALL_QUEUE")) s->smallQueueFactor = std::max(0, std::atoi(e));
 	if (const char* e = std::getenv("RTX_LONG_VISITS")) s->longVisits = std::atoi(e) > 0 ? std::atoi(e) : INT_MAX;
 	if (const char* e = std::getenv("RTX_MERGE_BLOCKS")) s->mergeBlocks = std::max(1ll, std::atoll(e));
 	if (const char* e = std::getenv("RTX_TRACE_TRI_BATCH")) s->traceTriBatch = std::max(1, std::min(64, std::atoi(e)));
