@@ -893,6 +893,14 @@ RTX_API int rtx_scene_set_triangles(rtx_scene* s, const void* triangles, uint32_
 
 RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n) {
 	if (!s || !linear_nodes) return fail(RTX_ERR_ARG, "null argument");
+	const bool timing = std::getenv("RTX_TRACE_DEBUG") != nullptr;
+	auto tPrev = std::chrono::steady_clock::now();
+	auto lap = [&](const char* what) {
+		if (!timing) return;
+		const auto now = std::chrono::steady_clock::now();
+		std::fprintf(stderr, "[rtx] set_bvh: %-28s %.3f s\n", what, std::chrono::duration<double>(now - tPrev).count());
+		tPrev = now;
+	};
 	if (!s->haveTris) return fail(RTX_ERR_STATE, "rtx_scene_set_triangles must come first");
 	if (n == 0) return fail(RTX_ERR_ARG, "a tree has at least its root");
 	const HostNode* N = (const HostNode*)linear_nodes;
@@ -934,6 +942,7 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 	if ((uint32_t)nextRank != ntri) return fail(RTX_ERR_ARG, "tree does not hold every triangle exactly once");
 	if (maxDepth > 32) return fail(RTX_ERR_ARG, "tree deeper than 32 levels");
 
+	lap("ranks (reference DFS)");
 	// Pass 2: pair records.  Pair 0 holds the root alone; every interior node with at least one
 	// child owns one pair, numbered breadth-first.
 	std::vector<int> pairOf(n, 0);
@@ -978,6 +987,7 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 		if (nd.right > 0) put(k + 1, 1, nd.right, code_of(nd.right));
 	}
 
+	lap("pair records");
 	// Pass 3: the 4-wide collapse walked by k_trace_wide.  The wide node of a binary interior node X holds
 	// X's grandchildren, and X's children where those are leaves.  It may only be used when boxes nest
 	// exactly and leaf boxes are the triangles' own bounds, which is what the reference's builder
@@ -1001,6 +1011,7 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 				if (!(N[ch].bmin[c] >= nd.bmin[c]) || !(N[ch].bmax[c] <= nd.bmax[c])) wideOk = false;
 		}
 	}
+	lap("premise check");
 	std::vector<float> wide;
 	int wideStackNeed = 1;
 	const char* treeKind = "none";
@@ -1019,8 +1030,11 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 			}
 			std::vector<rtxwide::BinNode> own;
 			const int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+			lap("triangle boxes");
 			rtxwide::build_sah(box, (int)ntri, own, threads);
-			built = rtxwide::collapse_wide(own, rankOf, wide, wideStackNeed);
+			lap("surface-area tree");
+			built = rtxwide::collapse_wide(own, rankOf, wide, wideStackNeed, threads);
+			lap("4-wide collapse + quantise");
 			treeKind = "surface-area";
 		}
 		if (!built) {
@@ -1042,6 +1056,7 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 		std::fprintf(stderr, "[rtx] wide tree (%s): ok %d, %zu nodes, stack need %d (binary: %zu pairs, stack need %d)\n", treeKind,
 					 (int)wideOk, wide.size() / 16, wideStackNeed, npairs, maxInteriorDepth + 1);
 
+	lap("-");
 	// Triangle records in rank order.
 	std::vector<float4> th((size_t)std::max<uint32_t>(ntri, 1) * 4), ts((size_t)std::max<uint32_t>(ntri, 1) * 8);
 	for (uint32_t i = 0; i < ntri; ++i) {
@@ -1074,6 +1089,7 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 		ts[r * 8 + 5] = make_float4(t.uv[2][0], t.uv[2][1], 0.0f, 0.0f);
 	}
 
+	lap("triangle records");
 	HIPCHK(hipSetDevice(s->device));
 	HIPCHK(s->dPairs.alloc(pairs.size()));
 	HIPCHK(hipMemcpy(s->dPairs.p, pairs.data(), pairs.size() * sizeof(float4), hipMemcpyHostToDevice));
@@ -1088,6 +1104,7 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 	HIPCHK(hipMemcpy(s->dTriHit.p, th.data(), th.size() * sizeof(float4), hipMemcpyHostToDevice));
 	HIPCHK(s->dTriShade.alloc(ts.size()));
 	HIPCHK(hipMemcpy(s->dTriShade.p, ts.data(), ts.size() * sizeof(float4), hipMemcpyHostToDevice));
+	lap("copies to the device");
 	s->rankOf.swap(rankOf);
 	s->numPairs = (uint32_t)npairs;
 	s->treeDepth = maxDepth + 1;  // + the root-only pair

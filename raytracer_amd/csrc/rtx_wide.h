@@ -216,7 +216,8 @@ inline void build_sah(const std::vector<float>& box, int ntri, std::vector<BinNo
 // A node's children are found by opening, largest surface first, the interior children of the binary
 // node until there are four.  stackNeed: entries a traversal may have waiting when it takes the nearest
 // child directly and stacks the others.  Returns false when a box cannot be represented.
-inline bool collapse_wide(const std::vector<BinNode>& N, const std::vector<int>& rankOf, std::vector<float>& out, int& stackNeed) {
+inline bool collapse_wide(const std::vector<BinNode>& N, const std::vector<int>& rankOf, std::vector<float>& out, int& stackNeed,
+						  int nthreads = 1) {
 	auto interior = [&](int i) { return N[i].tri < 0 && (N[i].left >= 0 || N[i].right >= 0); };
 	auto usable = [&](int i) { return i >= 0 && (N[i].tri >= 0 || interior(i)); };
 	auto members = [&](int x, int m[4]) {
@@ -249,74 +250,105 @@ inline bool collapse_wide(const std::vector<BinNode>& N, const std::vector<int>&
 		}
 		return k;
 	};
-	std::vector<int> wideOf(N.size(), 0), worder;
+	// Pass 1 (serial, breadth first): which binary nodes become wide nodes, and each one's members.
+	std::vector<int> wideOf(N.size(), 0), worder, mem;
+	std::vector<uint8_t> cnt;
 	worder.push_back(0);
 	for (size_t h = 0; h < worder.size(); ++h) {
-		int m[4];
+		int m[4] = {-1, -1, -1, -1};
 		const int k = members(worder[h], m);
 		for (int c = 0; c < k; ++c)
 			if (N[m[c]].tri < 0) {
 				wideOf[m[c]] = (int)worder.size();
 				worder.push_back(m[c]);
 			}
+		mem.insert(mem.end(), m, m + 4);
+		cnt.push_back((uint8_t)k);
 	}
-	out.assign(worder.size() * 16, 0.0f);
-	std::vector<int> need(worder.size(), 0);
-	bool ok = true;
+	const size_t nw = worder.size();
+	out.assign(nw * 16, 0.0f);
 	auto bits = [](uint32_t u) {
 		float f;
 		std::memcpy(&f, &u, 4);
 		return f;
 	};
-	for (size_t h = worder.size(); h-- > 0;) {
-		int m[4];
-		const int k = members(worder[h], m);
-		double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-		for (int c = 0; c < k; ++c)
-			for (int a = 0; a < 3; ++a) {
-				lo[a] = c ? std::min(lo[a], (double)N[m[c]].bmin[a]) : (double)N[m[c]].bmin[a];
-				hi[a] = c ? std::max(hi[a], (double)N[m[c]].bmax[a]) : (double)N[m[c]].bmax[a];
-			}
-		uint32_t q[6] = {0, 0, 0, 0, 0, 0};  // lo.x hi.x lo.y hi.y lo.z hi.z
-		float steps[3];
-		for (int a = 0; a < 3; ++a) {
-			// smallest power-of-two step with 254 steps >= extent (one step of slack for the rounding of
-			// the double arithmetic below), with a biased float exponent in 1..254
-			int e = 1;
-			while (e < 254 && 254.0 * std::ldexp(1.0, e - 127) < hi[a] - lo[a]) ++e;
-			const double step = std::ldexp(1.0, e - 127);
-			if (254.0 * step < hi[a] - lo[a]) ok = false;
-			steps[a] = (float)step;
-			for (int c = 0; c < 4; ++c) {
-				if (c >= k) {  // absent child: an empty interval, which no ray enters
-					q[a * 2 + 0] |= 255u << (8 * c);
-					continue;
+	// Pass 2 (independent per node, threads over ranges): boxes, steps, quantised bounds, codes.
+	std::vector<uint8_t> bad((size_t)std::max(1, nthreads), 0);
+	auto quantise = [&](size_t h0, size_t h1, int tid) {
+		for (size_t h = h0; h < h1; ++h) {
+			const int* m = &mem[h * 4];
+			const int k = cnt[h];
+			double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+			for (int c = 0; c < k; ++c)
+				for (int a = 0; a < 3; ++a) {
+					lo[a] = c ? std::min(lo[a], (double)N[m[c]].bmin[a]) : (double)N[m[c]].bmin[a];
+					hi[a] = c ? std::max(hi[a], (double)N[m[c]].bmax[a]) : (double)N[m[c]].bmax[a];
 				}
-				const double cmin = N[m[c]].bmin[a], cmax = N[m[c]].bmax[a];
-				uint32_t l = (uint32_t)std::min(255.0, std::max(0.0, std::floor((cmin - lo[a]) / step)));
-				uint32_t u = (uint32_t)std::min(255.0, std::max(0.0, std::ceil((cmax - lo[a]) / step)));
-				// A rounded double sum that compares strictly beyond a float proves the exact sum is at or
-				// beyond it; move outwards until that holds (the ends of the range hold by construction).
-				while (l > 0 && !(lo[a] + l * step < cmin)) --l;
-				while (u < 255 && !(lo[a] + u * step > cmax)) ++u;
-				q[a * 2 + 0] |= l << (8 * c);
-				q[a * 2 + 1] |= u << (8 * c);
+			uint32_t q[6] = {0, 0, 0, 0, 0, 0};  // lo.x hi.x lo.y hi.y lo.z hi.z
+			float steps[3];
+			for (int a = 0; a < 3; ++a) {
+				// smallest power-of-two step with 254 steps >= extent (one step of slack for the rounding of
+				// the double arithmetic below), with a biased float exponent in 1..254
+				const double ext = hi[a] - lo[a];
+				int e = 1;
+				if (ext > 0.0) {
+					int x;
+					(void)std::frexp(ext / 254.0, &x);  // ext/254 = f * 2^x, f in [0.5, 1)
+					e = std::min(254, std::max(1, x - 1 + 127));
+				}
+				while (e > 1 && 254.0 * std::ldexp(1.0, e - 1 - 127) >= ext) --e;
+				while (e < 254 && 254.0 * std::ldexp(1.0, e - 127) < ext) ++e;
+				const double step = std::ldexp(1.0, e - 127);
+				if (254.0 * step < ext) bad[tid] = 1;
+				steps[a] = (float)step;
+				for (int c = 0; c < 4; ++c) {
+					if (c >= k) {  // absent child: an empty interval, which no ray enters
+						q[a * 2 + 0] |= 255u << (8 * c);
+						continue;
+					}
+					const double cmin = N[m[c]].bmin[a], cmax = N[m[c]].bmax[a];
+					uint32_t l = (uint32_t)std::min(255.0, std::max(0.0, std::floor((cmin - lo[a]) / step)));
+					uint32_t u = (uint32_t)std::min(255.0, std::max(0.0, std::ceil((cmax - lo[a]) / step)));
+					// A rounded double sum that compares strictly beyond a float proves the exact sum is at or
+					// beyond it; move outwards until that holds (the ends of the range hold by construction).
+					while (l > 0 && !(lo[a] + l * step < cmin)) --l;
+					while (u < 255 && !(lo[a] + u * step > cmax)) ++u;
+					q[a * 2 + 0] |= l << (8 * c);
+					q[a * 2 + 1] |= u << (8 * c);
+				}
 			}
+			int code[4] = {0, 0, 0, 0};
+			for (int c = 0; c < k; ++c) code[c] = N[m[c]].tri >= 0 ? ~rankOf[N[m[c]].tri] : wideOf[m[c]];
+			float* w = &out[h * 16];
+			w[0] = (float)lo[0]; w[1] = (float)lo[1]; w[2] = (float)lo[2]; w[3] = steps[0];
+			w[4] = bits(q[0]); w[5] = bits(q[1]); w[6] = bits(q[2]); w[7] = bits(q[3]);
+			w[8] = bits(q[4]); w[9] = bits(q[5]); w[10] = bits((uint32_t)code[0]); w[11] = bits((uint32_t)code[1]);
+			w[12] = bits((uint32_t)code[2]); w[13] = bits((uint32_t)code[3]); w[14] = steps[1]; w[15] = steps[2];
 		}
-		int code[4] = {0, 0, 0, 0}, deepest = 0;
-		for (int c = 0; c < k; ++c) {
-			if (N[m[c]].tri >= 0) code[c] = ~rankOf[N[m[c]].tri];
-			else {
-				code[c] = wideOf[m[c]];
-				deepest = std::max(deepest, need[wideOf[m[c]]]);
-			}
+	};
+	if (nthreads > 1 && nw >= 65536) {
+		std::vector<std::thread> th;
+		const size_t per = (nw + (size_t)nthreads - 1) / (size_t)nthreads;
+		for (int t = 0; t < nthreads; ++t) {
+			const size_t h0 = std::min(nw, per * (size_t)t), h1 = std::min(nw, h0 + per);
+			if (h0 < h1) th.emplace_back(quantise, h0, h1, t);
 		}
+		for (auto& t : th) t.join();
+	}
+	else
+		quantise(0, nw, 0);
+	bool ok = true;
+	for (uint8_t b : bad) ok = ok && !b;
+	// Pass 3 (serial, children before parents: a child's number is larger than its parent's): entries a
+	// traversal may have waiting.
+	std::vector<int> need(nw, 0);
+	for (size_t h = nw; h-- > 0;) {
+		const int* m = &mem[h * 4];
+		const int k = cnt[h];
+		int deepest = 0;
+		for (int c = 0; c < k; ++c)
+			if (N[m[c]].tri < 0) deepest = std::max(deepest, need[wideOf[m[c]]]);
 		need[h] = std::max(0, k - 1) + deepest;
-		float* w = &out[h * 16];
-		w[0] = (float)lo[0]; w[1] = (float)lo[1]; w[2] = (float)lo[2]; w[3] = steps[0];
-		w[4] = bits(q[0]); w[5] = bits(q[1]); w[6] = bits(q[2]); w[7] = bits(q[3]);
-		w[8] = bits(q[4]); w[9] = bits(q[5]); w[10] = bits((uint32_t)code[0]); w[11] = bits((uint32_t)code[1]);
-		w[12] = bits((uint32_t)code[2]); w[13] = bits((uint32_t)code[3]); w[14] = steps[1]; w[15] = steps[2];
 	}
 	stackNeed = std::max(1, need[0]);
 	return ok;
