@@ -7,7 +7,7 @@
 A step is one frame (one iteration of the loop at /root/reference/src/RayTracer.cpp:234: four
 samples per pixel through the whole bounce loop, accumulated) of the Sponza-class procedural atrium
 (~263k triangles, textures, cube-map sky) at 1920x1080, max_recursion_depth 4, one diffuse and one
-specular ray per hit -- BASELINE config 3.  The scene, textures and BVH are resident on the GPU before
+specular ray per hit.  The scene, textures and BVH are resident on the GPU before
 the timed region.  With N > 1 the image tiles are interleaved over the ranks and a step is N consecutive
 frames, so every rank keeps the work of one whole frame per step (weak scaling: its 1/N tile share of N frames,
 which the library renders as one merged pixel batch); --scaling strong keeps one frame per step instead.

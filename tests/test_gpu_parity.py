@@ -2,7 +2,7 @@
 golden vectors taken from the reference.  Needs an MI355X: run with -m gpu.
 
 Bar: primary-hit triangle ids, t/alpha/beta, per-sample radiance and accumulators are all compared
-bit for bit (integer ids exactly; float32 values by their bit patterns).  At full BASELINE sizes,
+bit for bit (integer ids exactly; float32 values by their bit patterns).  At the full benchmark sizes,
 where the CPU restatement would take minutes, the checks are size-independent properties:
 culled traversal == exhaustive traversal, tile shares compose to the whole image, small work arenas
 give the same image as large ones, repeated runs are identical.
@@ -193,10 +193,10 @@ def test_empty_and_single_triangle_scenes(libs):
         assert_bits_equal(acc_o[..., :3], rt.accum()[..., :3], "accumulator n=%d" % n)
 
 
-# ---------------------------------------------------------------- properties at BASELINE sizes
+# ---------------------------------------------------------------- properties at the benchmark sizes
 
 def test_bunny_class_1080p_culled_equals_exhaustive(libs):
-    """BASELINE config 2 (bunny-class mesh, ~69.5k triangles, 1080p, primary rays): the production
+    """Primary rays only (bunny-class mesh, ~69.5k triangles, 1080p, primary rays): the production
     traversal returns the same triangle for every one of the 8.3M rays as the traversal that
     visits exactly the reference's candidate set; a 64x36 window is also checked against the CPU."""
     sc = scenes.bunny_class_scene()
@@ -298,6 +298,51 @@ def test_atrium_full_size_rows_equal_restatement(libs):
         O.render_rows(f, acc_o, row0=539, row1=542, nthreads=16)
     assert_bits_equal(acc_o[539:542, :, :3], full[539:542, :, :3], "rows 539..541 vs CPU")
     assert np.array_equal(rt.tonemap_read(2).reshape(-1, 3), api.tonemap(full, 2))
+
+
+def test_atrium_4k_tile_shares_compose(libs):
+    """The 4K multi-GPU configuration on one GPU: 3840x2160, depth 4, the image as one share, as two interleaved
+    shares, and as a 1/8 share rendered for two frames in one call (merged batches) against the same share frame by
+    frame; a window against the CPU restatement."""
+    sc = scenes.atrium_scene(width=3840, height=2160, max_depth=4)
+    nodes = api.build_bvh(sc.tris)
+    rt = api.RayTracer(0)
+    rt.load_scene(sc, nodes)
+    rt.reset()
+    rt.render(1, 1)
+    st = rt.stats()
+    assert st["rays_per_level"][0] == 3840 * 2160 * 4 and st["rays"] == sum(st["rays_per_level"])
+    full = rt.accum()
+    tiles_x = (sc.width + 63) // 64
+    ty, tx = np.meshgrid(np.arange(sc.height) // 64, np.arange(sc.width) // 64, indexing="ij")
+    owner = (ty * tiles_x + tx) % 2
+    merged = np.zeros_like(full)
+    rays = 0
+    for r in range(2):
+        rt.set_tiles(r, 2, -1)
+        rt.reset()
+        rt.render(1, 1)
+        rays += rt.stats()["rays"]
+        part = rt.accum()
+        assert not part[owner != r].any(), "a share wrote outside its tiles"
+        merged[owner == r] = part[owner == r]
+    assert_bits_equal(full, merged, "two shares")
+    assert rays == st["rays"]
+    rt.set_tiles(3, 8, -1)
+    rt.reset()
+    rt.render(1, 2)
+    assert rt.stats()["chunks"] == 1
+    both = rt.accum()
+    rt.reset()
+    rt.render(1, 1)
+    rt.render(2, 1)
+    assert_bits_equal(both, rt.accum(), "1/8 share, two frames merged")
+    O = binding.Oracle()
+    load_into(O, sc, build=False)
+    O.set_nodes(nodes)
+    acc_o = np.zeros((sc.height, sc.width, 4), np.float32)
+    O.render_rows(1, acc_o, row0=1079, row1=1081, nthreads=16)
+    assert_bits_equal(acc_o[1079:1081, :, :3], full[1079:1081, :, :3], "rows 1079..1080 vs CPU")
 
 
 def test_external_accumulator_and_resume(libs):
