@@ -466,14 +466,14 @@ int launch_trace(rtx_scene* s, const DevScene& d, bool anyhit, bool exhaustive, 
 					: launch_exact_t<false, false>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, nullptr, nullptr, nDev);
 	else if (anyhit) {
 		rc = launch_wide_t<true>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, unsafeList, cnt + UNSAFE_SLOT, nDev, unsafeList + n, cnt + LONG_SLOT);
-		if (rc == RTX_OK && s->longVisits != INT_MAX && !std::getenv("RTX_LONG_SKIP"))
+		if (rc == RTX_OK && s->longVisits != INT_MAX)
 			rc = launch_long_t<true>(s, d, ro, rd, hits, unsafeList + n, cnt + LONG_SLOT, unsafeList, cnt + UNSAFE_SLOT);
 		if (rc == RTX_OK)
 			rc = launch_exact_t<true, false>(s, d, ro, rd, hits, n, cnt + WORK2_SLOT, unsafeList, cnt + UNSAFE_SLOT, nullptr);
 	}
 	else {
 		rc = launch_wide_t<false>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, unsafeList, cnt + UNSAFE_SLOT, nDev, unsafeList + n, cnt + LONG_SLOT);
-		if (rc == RTX_OK && s->longVisits != INT_MAX && !std::getenv("RTX_LONG_SKIP"))
+		if (rc == RTX_OK && s->longVisits != INT_MAX)
 			rc = launch_long_t<false>(s, d, ro, rd, hits, unsafeList + n, cnt + LONG_SLOT, unsafeList, cnt + UNSAFE_SLOT);
 		if (rc == RTX_OK)
 			rc = launch_exact_t<false, false>(s, d, ro, rd, hits, n, cnt + WORK2_SLOT, unsafeList, cnt + UNSAFE_SLOT, nullptr);
