@@ -112,11 +112,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d (launch N>1 through torch.distributed.run)" % (args.gpus, world))
+    # RTX_BENCH_BACKEND=gloo rehearses the N > 1 flow on a box with fewer GPUs than ranks (ranks then share devices
+    # and the gather travels through the host); the measured configuration is one rank per GPU over RCCL.
+    backend = os.environ.get("RTX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     sc = scenes.atrium_scene(width=args.width, height=args.height, max_depth=args.depth)
     nodes = api.build_bvh(sc.tris)
@@ -218,6 +226,7 @@ def main():
             "config": {"workload": "atrium (Sponza-class, %d triangles, %d textures + cube-map sky) %dx%d, 4 spp per step, "
                                    "max_recursion_depth %d, diffuse 1, specular 1" % (len(sc.tris), len(sc.textures), sc.width, sc.height, sc.max_depth),
                        "frames_per_step": frames_per_step,
+                       "backend": "rccl" if backend == "nccl" else backend,
                        "sharding": "tile-interleave x%d, %s" % (world, "gather to rank 0 per step" if args.balance == "static" else "dynamic batches + reduce per step")},
             "samples_per_s": round(samples / dt, 1),
             "rays_per_step": round(rays_total / args.steps),
@@ -231,7 +240,7 @@ def main():
             # tree it visits, one 64-B record per triangle whose quantised box it enters, 32 B ray in, 16 B hit out
             # (a ray that is not traversed has only its direction read: 16 B less)
             bytes_per_ray = 64.0 * n_wide + 64.0 * n_leaf + 48.0 - 16.0 * counters["untraced"] * world / max(rays_total, 1.0)
-            achieved = bytes_per_ray * rays_total / (trace_ms_sum / world * 1e-3) / 1e9 if trace_ms_sum > 0 else 0.0
+            achieved = bytes_per_ray * rays_total / (trace_ms_sum * 1e-3) / 1e9 if trace_ms_sum > 0 else 0.0  # per GPU: both sums run over the ranks
             out["roofline"] = {"bound": "hbm", "kernel": "k_trace_wide", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),
                                "node_visits_per_ray": round(n_wide, 2), "leaf_fetches_per_ray": round(n_leaf, 3),

@@ -79,9 +79,15 @@ class TileSharder:
         n_pix = self.width * self.height
         pack, place = self._plan(accum.device)
         send = accum.reshape(n_pix, c).index_select(0, pack)  # padding slots carry some pixel; rank 0 drops them
+        # gloo has no gather for device tensors: there (rehearsals on one GPU) the pieces travel through the host
+        staged = send.is_cuda and dist.get_backend(self.group) == "gloo"
+        if staged:
+            send = send.cpu()
         if self.rank == 0:
-            big = accum.new_empty((self.world, send.shape[0], c))
+            big = send.new_empty((self.world, send.shape[0], c))
             dist.gather(send, list(big.unbind(0)), dst=0, group=self.group)
+            if staged:
+                big = big.to(accum.device)
             out = accum.new_empty((n_pix + 1, c))
             out.index_copy_(0, place, big.reshape(-1, c))
             return out[:n_pix].reshape(self.height, self.width, c)
