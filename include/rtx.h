@@ -137,7 +137,9 @@ int rtx_accum_reset(rtx_scene* s);
 /* The loop body of RayTracer::render for frames i = first_frame .. first_frame+n_frames-1
  * (1-based like `i` at src/RayTracer.cpp:234): camera rays, traversal, intersection, bounce
  * loop, accumulateImg(row,col) += sum*0.25f (src/RayTracer.cpp:237-246).  The tone map is
- * rtx_tonemap_read (or the caller's own); the PNG write stays with the caller. */
+ * rtx_tonemap_read (or the caller's own); the PNG write stays with the caller.
+ * With n_frames > 1 the frames of a small tile share are rendered together in merged pixel batches; every
+ * pixel still receives its frames in ascending order, so the accumulator equals that of n_frames calls. */
 int rtx_render_frames(rtx_scene* s, uint32_t first_frame, uint32_t n_frames);
 
 /* Copies the accumulator to host memory: height*width*4 floats. */
