@@ -65,6 +65,9 @@ def test_primary_hits_match_reference_goldens(libs, name):
     (2, 70, 45, 2, 1, 2, False),
     (3, 33, 129, 4, 1, 1, True),      # ragged: neither a multiple of 4 nor of 64
     (4, 64, 64, 1, 3, 2, True),       # depth 1: children are pure occlusion queries
+    (5, 16, 12, 15, 1, 1, True),      # the deepest recursion the ABI accepts
+    (6, 24, 16, 1, 64, 64, False),    # the most rays per hit the ABI accepts
+    (7, 20, 12, 2, 64, 1, True),
 ])
 def test_radiance_and_accumulator_bit_exact(libs, seed, w, h, depth, nd, ns, sky):
     sc = scenes.mixed_scene(seed=seed, width=w, height=h, max_depth=depth, n_diff=nd, n_spec=ns, with_sky=sky)
