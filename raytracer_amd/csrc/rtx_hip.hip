@@ -125,8 +125,9 @@ struct DevBuf {
 
 struct EventPair {
 	hipEvent_t a, b;
-	int kind;   // 0 trace, 1 shade/gather/accumulate, 2 whole call
-	int level;  // path level of a trace launch
+	int kind;    // 0 trace, 1 shade/gather/accumulate, 2 whole call
+	int level;   // path level of a trace launch
+	bool ended;  // b has been recorded
 };
 
 }  // namespace
@@ -189,7 +190,9 @@ struct rtx_scene {
 	DevBuf<unsigned long long> dStats;  // node tests, tri tests
 	unsigned* hCounts = nullptr;        // pinned
 	unsigned long long* hStats = nullptr;
-	std::vector<EventPair> events;
+	std::vector<EventPair> events;       // pairs recorded since the last harvest
+	std::vector<hipEvent_t> eventPool;   // events waiting to be used again (created on demand, destroyed with the scene)
+	bool timeEvents = true;              // false: kernels are launched without timing events
 	rtx_stats stats;
 
 	~rtx_scene() {
@@ -202,6 +205,7 @@ struct rtx_scene {
 			(void)hipEventDestroy(e.a);
 			(void)hipEventDestroy(e.b);
 		}
+		for (hipEvent_t e : eventPool) (void)hipEventDestroy(e);
 		if (ownStream) (void)hipStreamDestroy(ownStream);
 	}
 };
@@ -330,44 +334,76 @@ int ensure_ready(rtx_scene* s, bool needCamera) {
 // for the widest level: origin (16) + direction (16) + hit (16).
 constexpr size_t NODE_BYTES = 24, RAY_BYTES = 48;
 
-struct EventScope {
-	rtx_scene* s;
-	size_t idx;
-};
+constexpr size_t NO_EVENT = ~(size_t)0;
 
+int take_event(rtx_scene* s, hipEvent_t& e) {
+	if (!s->eventPool.empty()) {
+		e = s->eventPool.back();
+		s->eventPool.pop_back();
+		return RTX_OK;
+	}
+	HIPCHK(hipEventCreate(&e));
+	return RTX_OK;
+}
+
+// Timing events come from a pool that lives as long as the scene: a launch inside the timed region costs two
+// hipEventRecord calls and nothing else.
 int begin_event(rtx_scene* s, int kind, size_t& idx, int level = 0) {
+	idx = NO_EVENT;
+	if (!s->timeEvents) return RTX_OK;
 	EventPair e;
-	HIPCHK(hipEventCreate(&e.a));
-	HIPCHK(hipEventCreate(&e.b));
+	int rc = take_event(s, e.a);
+	if (rc) return rc;
+	rc = take_event(s, e.b);
+	if (rc) {
+		s->eventPool.push_back(e.a);
+		return rc;
+	}
 	e.kind = kind;
 	e.level = level;
+	e.ended = false;
 	s->events.push_back(e);
 	idx = s->events.size() - 1;
 	HIPCHK(hipEventRecord(e.a, s->stream));
 	return RTX_OK;
 }
 int end_event(rtx_scene* s, size_t idx) {
+	if (idx == NO_EVENT) return RTX_OK;
 	HIPCHK(hipEventRecord(s->events[idx].b, s->stream));
+	s->events[idx].ended = true;
 	return RTX_OK;
 }
-// After a stream sync: fold event durations into the stats and recycle the events.
-int harvest_events(rtx_scene* s) {
+// Puts every recorded pair back into the pool without reading it: what an error path and the start of a call do,
+// so that a pair whose second event was never recorded cannot poison a later harvest.
+void drop_events(rtx_scene* s) {
 	for (auto& e : s->events) {
-		float ms = 0.0f;
-		HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
-		if (e.kind == 0) {
-			s->stats.trace_ms += ms;
-			s->stats.trace_ms_per_level[e.level & 15] += ms;
-			s->stats.trace_launches++;
-		}
-		else if (e.kind == 1)
-			s->stats.shade_ms += ms;
-		else
-			s->stats.total_ms += ms;
-		(void)hipEventDestroy(e.a);
-		(void)hipEventDestroy(e.b);
+		s->eventPool.push_back(e.a);
+		s->eventPool.push_back(e.b);
 	}
 	s->events.clear();
+}
+// After a stream sync: fold event durations into the stats and recycle the events.  The list is emptied whether
+// or not every pair could be read.
+int harvest_events(rtx_scene* s) {
+	hipError_t bad = hipSuccess;
+	for (auto& e : s->events) {
+		float ms = 0.0f;
+		const hipError_t err = e.ended ? hipEventElapsedTime(&ms, e.a, e.b) : hipSuccess;
+		if (err != hipSuccess) bad = err;
+		else if (e.ended) {
+			if (e.kind == 0) {
+				s->stats.trace_ms += ms;
+				s->stats.trace_ms_per_level[e.level & 15] += ms;
+				s->stats.trace_launches++;
+			}
+			else if (e.kind == 1)
+				s->stats.shade_ms += ms;
+			else
+				s->stats.total_ms += ms;
+		}
+	}
+	drop_events(s);
+	if (bad != hipSuccess) return fail(RTX_ERR_DEVICE, std::string("hipEventElapsedTime: ") + hipGetErrorString(bad));
 	return RTX_OK;
 }
 
@@ -768,6 +804,7 @@ int finish_stats(rtx_scene* s) {
 
 int begin_call(rtx_scene* s) {
 	std::memset(&s->stats, 0, sizeof(s->stats));
+	drop_events(s);  // pairs an earlier call left behind when it failed half-way
 	if (s->instrumented) HIPCHK(hipMemsetAsync(s->dStats.p, 0, 12 * sizeof(unsigned long long), s->stream));
 	return RTX_OK;
 }
@@ -1184,22 +1221,31 @@ RTX_API int rtx_render_frames(rtx_scene* s, uint32_t first_frame, uint32_t n_fra
 	if (rc) return rc;
 	rc = begin_call(s);
 	if (rc) return rc;
-	size_t evTotal;
-	rc = begin_event(s, 2, evTotal);
+	// the pair around the whole call is kept apart from the list the per-batch harvests empty
+	hipEvent_t totalA, totalB;
+	rc = take_event(s, totalA);
 	if (rc) return rc;
-	// the total-time event pair must survive the per-batch harvests: park it
-	EventPair total = s->events.back();
-	s->events.pop_back();
-	rc = render_batches(s, first_frame, n_frames, 0, 0, nullptr, nullptr, nullptr);
+	rc = take_event(s, totalB);
 	if (rc) {
-		(void)hipEventDestroy(total.a);
-		(void)hipEventDestroy(total.b);
+		s->eventPool.push_back(totalA);
 		return rc;
 	}
-	s->events.push_back(total);
-	rc = end_event(s, s->events.size() - 1);
-	if (rc) return rc;
-	HIPCHK(hipStreamSynchronize(s->stream));
+	hipError_t e = hipEventRecord(totalA, s->stream);
+	if (e == hipSuccess) {
+		rc = render_batches(s, first_frame, n_frames, 0, 0, nullptr, nullptr, nullptr);
+		if (rc == RTX_OK) e = hipEventRecord(totalB, s->stream);
+		if (rc == RTX_OK && e == hipSuccess) e = hipStreamSynchronize(s->stream);
+		float ms = 0.0f;
+		if (rc == RTX_OK && e == hipSuccess) e = hipEventElapsedTime(&ms, totalA, totalB);
+		s->stats.total_ms = ms;
+	}
+	s->eventPool.push_back(totalA);
+	s->eventPool.push_back(totalB);
+	if (rc) {
+		drop_events(s);
+		return rc;
+	}
+	if (e != hipSuccess) return fail(RTX_ERR_DEVICE, hipGetErrorString(e));
 	rc = harvest_events(s);
 	if (rc) return rc;
 	return finish_stats(s);
