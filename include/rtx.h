@@ -170,6 +170,19 @@ int rtx_primary_hits(rtx_scene* s, int mode, int32_t* tri_ids, float* t_alpha_be
 int rtx_trace_rays(rtx_scene* s, int mode, uint32_t n, const float* origins, const float* directions,
 				   int32_t* tri_ids, float* t_alpha_beta);
 
+/* rtx_trace_rays for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  It has no counterpart in the reference.  The four arrays are DEVICE memory of the
+ * scene's GPU, laid out as for rtx_trace_rays (d_t_alpha_beta may be NULL); the call itself allocates nothing
+ * on the device or through the runtime: ray records, hit records, the traversal's ray lists and its counters
+ * live in a fixed array inside the library (14 MiB per GPU, held until the process ends), which limits one call
+ * to RTX_NOALLOC_MAX_RAYS rays; more is RTX_ERR_ARG.  The scene needs its triangles and its tree, nothing else.
+ * Work is enqueued on the scene's stream (the default stream if none was set) and the call blocks until it has
+ * finished.  All scenes of one GPU share that GPU's array: calls that overlap on one GPU race.  No timing and
+ * no test counters are taken (rtx_get_stats reports the ray count only). */
+#define RTX_NOALLOC_MAX_RAYS (1u << 18)
+int rtx_trace_rays_noalloc(rtx_scene* s, int mode, uint32_t n, const float* d_origins, const float* d_directions,
+						   int32_t* d_tri_ids, float* d_t_alpha_beta);
+
 /* Per-sample radiance of one frame before accumulation, i.e. color(0, ray) for every
  * primary ray: out[height*width*4][4].  Tiles outside the scene's tile set are left untouched. */
 int rtx_sample_radiance(rtx_scene* s, uint32_t frame, float* host_out);

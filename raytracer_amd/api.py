@@ -65,6 +65,7 @@ HIP_SYMBOLS = {
     "rtx_tonemap_read": (_i, [_vp, _i, _vp]),
     "rtx_primary_hits": (_i, [_vp, _i, _ip, _fp]),
     "rtx_trace_rays": (_i, [_vp, _i, _u32, _fp, _fp, _ip, _fp]),
+    "rtx_trace_rays_noalloc": (_i, [_vp, _i, _u32, _vp, _vp, _vp, _vp]),
     "rtx_sample_radiance": (_i, [_vp, _u32, _fp]),
     "rtx_scene_set_instrumented": (_i, [_vp, _i]),
     "rtx_get_stats": (_i, [_vp, C.POINTER(Stats)]),
@@ -329,6 +330,10 @@ class RayTracer:
         _chk(self.lib.rtx_trace_rays(self.h, mode, len(o), _p(o.reshape(-1)), _p(d.reshape(-1)),
                                      ids.ctypes.data_as(_ip), _p(tab.reshape(-1))))
         return ids, tab
+
+    def trace_rays_noalloc(self, n, d_origins, d_directions, d_tri_ids, d_t_alpha_beta=None, mode=0):
+        """rtx_trace_rays_noalloc: the four arguments are device addresses (ints) on this scene's GPU."""
+        _chk(self.lib.rtx_trace_rays_noalloc(self.h, mode, n, d_origins, d_directions, d_tri_ids, d_t_alpha_beta))
 
     def sample_radiance(self, frame):
         out = np.zeros((self.height * self.width, 4, 4), np.float32)

@@ -528,6 +528,15 @@ __global__ __launch_bounds__(256) void k_export_hits(DevScene sc, Batch b, const
 	}
 }
 
+// xyz triples -> the 16-byte ray records the traversal reads (w = 0: a ray to be traced, no RNG key).
+__global__ __launch_bounds__(256) void k_pack_rays(int n, const float* __restrict__ o, const float* __restrict__ d,
+												   float4* __restrict__ rayO, float4* __restrict__ rayD) {
+	const int j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= n) return;
+	rayO[j] = make_float4(o[3 * (size_t)j], o[3 * (size_t)j + 1], o[3 * (size_t)j + 2], 0.0f);
+	rayD[j] = make_float4(d[3 * (size_t)j], d[3 * (size_t)j + 1], d[3 * (size_t)j + 2], 0.0f);
+}
+
 __global__ __launch_bounds__(256) void k_export_hits_linear(DevScene sc, int n, const float4* __restrict__ hits,
 															int* __restrict__ ids, float* __restrict__ tab) {
 	const int j = blockIdx.x * 256 + threadIdx.x;

@@ -47,6 +47,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -77,7 +78,37 @@ int fail(int code, const std::string& msg) {
 #include "rtx_dev_trace.h"
 #include "rtx_dev_shade.h"
 
+// ------------------------------------------------------------------------------------------------
+// Scratch memory of rtx_trace_rays_noalloc, the one entry point that allocates nothing: ray records, hit
+// records, the two ray lists of the traversal and its counter block live in this file-scope array instead of in
+// buffers from hipMalloc.  Every GPU the library runs on holds its own copy of the array until the process ends.
+// In host code the array's name is only a handle for hipGetSymbolAddress: the address a kernel may use is the
+// one that call returns, per device (scratch_for_device below), and host code passes that pointer and never
+// the name.
+constexpr size_t NOALLOC_COUNT_BYTES = 4096;                               // counter block of one traversal + fault word
+constexpr size_t NOALLOC_BYTES_PER_RAY = 16 + 16 + 16 + 8;                 // origin, direction, hit record, two list slots
+constexpr size_t NOALLOC_SCRATCH_BYTES = NOALLOC_COUNT_BYTES + (size_t)RTX_NOALLOC_MAX_RAYS * NOALLOC_BYTES_PER_RAY;  // 14 MiB + 4 KiB
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
 namespace {
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratchMutex;
+unsigned char* g_scratchPtr[MAX_DEVICES] = {nullptr};
+
+// The device address of `scratch` on `device`, which must be the current device.  Looked up once per device.
+int scratch_for_device(int device, unsigned char** out) {
+	if (device < 0 || device >= MAX_DEVICES) return fail(RTX_ERR_ARG, "device id beyond the library's table of scratch arrays");
+	std::lock_guard<std::mutex> lk(g_scratchMutex);
+	if (!g_scratchPtr[device]) {
+		void* p = nullptr;
+		HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+		if (!p) return fail(RTX_ERR_DEVICE, "hipGetSymbolAddress returned no address for the scratch array");
+		g_scratchPtr[device] = (unsigned char*)p;
+	}
+	*out = g_scratchPtr[device];
+	return RTX_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Host side of the library.
@@ -192,7 +223,8 @@ struct rtx_scene {
 	unsigned long long* hStats = nullptr;
 	std::vector<EventPair> events;       // pairs recorded since the last harvest
 	std::vector<hipEvent_t> eventPool;   // events waiting to be used again (created on demand, destroyed with the scene)
-	bool timeEvents = true;              // false: kernels are launched without timing events
+	unsigned char* noallocScratch = nullptr;  // this device's copy of the file-scope scratch array
+	bool timeEvents = true;              // false: kernels are launched without timing events (the entry point that allocates nothing)
 	rtx_stats stats;
 
 	~rtx_scene() {
@@ -831,6 +863,13 @@ RTX_API int rtx_scene_create(rtx_scene** out, int device) {
 	rtx_scene* s = new (std::nothrow) rtx_scene();
 	if (!s) return fail(RTX_ERR_MEMORY, "out of host memory");
 	s->device = device;
+	{
+		const int rc = scratch_for_device(device, &s->noallocScratch);
+		if (rc) {
+			delete s;
+			return rc;
+		}
+	}
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->numCUs = prop.multiProcessorCount;
 	if (const char* e = std::getenv("RTX_TRACE_REFILL")) s->traceRefill = std::max(1, std::min(64, std::atoi(e)));
@@ -1393,6 +1432,52 @@ RTX_API int rtx_trace_rays(rtx_scene* s, int mode, uint32_t n, const float* orig
 	s->stats.rays = n;
 	s->stats.rays_per_level[0] = n;
 	return finish_stats(s);
+}
+
+RTX_API int rtx_trace_rays_noalloc(rtx_scene* s, int mode, uint32_t n, const float* d_origins, const float* d_directions,
+								   int32_t* d_tri_ids, float* d_t_alpha_beta) {
+	if (!s || !d_origins || !d_directions || !d_tri_ids) return fail(RTX_ERR_ARG, "null argument");
+	if (mode != 0 && mode != 1) return fail(RTX_ERR_ARG, "mode must be 0 or 1");
+	if (n > RTX_NOALLOC_MAX_RAYS)
+		return fail(RTX_ERR_ARG, "rtx_trace_rays_noalloc takes at most " + std::to_string(RTX_NOALLOC_MAX_RAYS) + " rays per call (" +
+									 std::to_string(n) + " given): its work memory is a fixed array");
+	if (!s->haveTris || !s->haveBvh) return fail(RTX_ERR_STATE, "rtx_scene_set_triangles and rtx_scene_set_bvh must come first");
+	if (!s->noallocScratch) return fail(RTX_ERR_STATE, "the scene has no scratch array");
+	HIPCHK(hipSetDevice(s->device));
+	std::memset(&s->stats, 0, sizeof(s->stats));
+	if (n == 0) return RTX_OK;
+	// carve the array: counters | origins | directions | hit records | set-aside list and list of long rays
+	unsigned char* base = s->noallocScratch;
+	unsigned* counts = (unsigned*)base;
+	float4* rayO = (float4*)(base + NOALLOC_COUNT_BYTES);
+	float4* rayD = rayO + RTX_NOALLOC_MAX_RAYS;
+	float4* hits = rayD + RTX_NOALLOC_MAX_RAYS;
+	int* lists = (int*)(hits + RTX_NOALLOC_MAX_RAYS);
+	static_assert(COUNT_WORDS * sizeof(unsigned) <= NOALLOC_COUNT_BYTES, "counter block");
+	DevScene d = make_dev_scene(s);
+	d.fault = counts + FAULT_WORD;
+	// the array keeps the last call's contents: the cursors, list lengths and the fault word must start at zero
+	HIPCHK(hipMemsetAsync(counts, 0, NOALLOC_COUNT_BYTES, s->stream));
+	hipLaunchKernelGGL(k_pack_rays, dim3((n + 255) / 256), dim3(256), 0, s->stream, (int)n, d_origins, d_directions, rayO, rayD);
+	HIPCHK(hipGetLastError());
+	// no timing events and no test counters: both would need memory of their own
+	const bool savedTime = s->timeEvents, savedInstr = s->instrumented;
+	s->timeEvents = false;
+	s->instrumented = false;
+	int rc = launch_trace(s, d, false, mode == 1, rayO, rayD, hits, (int)n, counts, lists);
+	s->timeEvents = savedTime;
+	s->instrumented = savedInstr;
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_export_hits_linear, dim3((n + 255) / 256), dim3(256), 0, s->stream, d, (int)n, hits, d_tri_ids, d_t_alpha_beta);
+	HIPCHK(hipGetLastError());
+	unsigned faultBits = 0;
+	HIPCHK(hipMemcpyAsync(&faultBits, counts + FAULT_WORD, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+	HIPCHK(hipStreamSynchronize(s->stream));
+	rc = check_fault(faultBits);
+	if (rc) return rc;
+	s->stats.rays = n;
+	s->stats.rays_per_level[0] = n;
+	return RTX_OK;
 }
 
 RTX_API int rtx_sample_radiance(rtx_scene* s, uint32_t frame, float* host_out) {
