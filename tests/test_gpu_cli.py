@@ -176,6 +176,99 @@ render_num %d
     assert want.std() > 10
 
 
+def ball_mesh(rings, segs, radius, seed):
+    """Indexed lat-long ball with a little relief, open by a hair at the poles (no zero-area faces), radial normals."""
+    rng = np.random.default_rng(seed)
+    ph = rng.uniform(0, 6.28, 2)
+    th, pp = np.meshgrid(np.linspace(0.02, np.pi - 0.02, rings + 1), np.linspace(0, 2 * np.pi, segs + 1), indexing="ij")
+    r = radius * (1.0 + 0.06 * np.sin(4 * th + ph[0]) * np.cos(5 * pp + ph[1]))
+    d = np.stack([np.sin(th) * np.cos(pp), np.cos(th), np.sin(th) * np.sin(pp)], -1)
+    verts = (r[..., None] * d).reshape(-1, 3).astype(F)
+    nrm = d.reshape(-1, 3).astype(F)
+    uvs = np.stack([pp / (2 * np.pi), th / np.pi], -1).reshape(-1, 2).astype(F)
+    i, j = np.meshgrid(np.arange(rings), np.arange(segs), indexing="ij")
+    a = (i * (segs + 1) + j).reshape(-1)
+    b, dd = a + segs + 1, a + 1
+    c = b + 1
+    faces = np.concatenate([np.stack([a, c, b], 1), np.stack([a, dd, c], 1)])
+    return verts, uvs, nrm, faces
+
+
+@pytest.mark.gpu
+def test_template_config_512_against_the_restatement(tmp_path):
+    """The reference's own config.txt (/root/reference/config.txt:1-63) with its comments removed as its first
+    line asks: frame 512 512, camera 50 50 0 -> origin at focal 400, black background, depth 2, two diffuse and
+    two specular rays, the placeholder model replaced by a generated 2,048-triangle mesh (metal, roughness 1,
+    override colour 0.8, as the template has it), the placeholder sky by six generated faces, the template's
+    floor triangle, render_num 4 (16 samples per pixel).  The command line renders it on the GPU; all four
+    out_NNN.png must equal, byte for byte, the tone-mapped accumulator of the CPU restatement of the reference."""
+    from util import load_into
+    assert os.path.exists(build.CLI_BIN), "raytracer_amd/RayTracer must be built before the GPU tests"
+    d = str(tmp_path)
+    W = H = 512
+    frames = 4
+    verts, uvs, nrm, faces = ball_mesh(32, 32, 1.5, 5)
+    assert len(faces) == 2048
+    write_obj(os.path.join(d, "model.obj"), verts, uvs, nrm, faces)
+    open(os.path.join(d, "m.mtl"), "w").write("newmtl a\nKd 0.3 0.3 0.3\n")
+    faces6 = scenes.sky_faces(64)
+    names = ["front", "back", "left", "right", "top", "bottom"]
+    for k, nm in enumerate(names):
+        binding.write_ppm(os.path.join(d, nm + ".ppm"), faces6[k])
+    cfg = """frame %d %d
+camera 50 50 0 0 0 0 400 0
+background_color 0 0 0
+max_recursion_depth 2
+diffuse_ray_number  2
+specular_ray_number 2
+skybox 1 front.ppm back.ppm left.ppm right.ppm top.ppm bottom.ppm
+model_start
+model_path model.obj
+texture_path no
+scale 1
+position_offset 0 0 0
+is_metal 1
+is_light_emitting 0
+is_transparent 0
+specular_roughness 1
+refractive_index 1.2
+override_color 0.8 0.8 0.8
+model_end
+triangle_start
+vertex_0 -1000 100 1000
+vertex_1 1000 100 1000
+vertex_2 0 100 -1000
+normal_side 0 -1 0
+color 1 1 1
+is_metal 0
+is_light_emitting 0
+is_transparent 0
+specular_roughness 0
+refractive_index 1.2
+triangle_end
+render_num %d
+""" % (W, H, frames)
+    open(os.path.join(d, "config.txt"), "w").write(cfg)
+    res = subprocess.run([build.CLI_BIN, "config.txt"], cwd=d, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    lines = res.stdout.strip().splitlines()
+    assert len(lines) == frames + 1 and lines[-1] == "Render finished", res.stdout
+
+    t1 = load_model_py(verts, None, nrm, faces, 1.0, (0, 0, 0), dict(color=(0.8, 0.8, 0.8), rough=1.0, ior=1.2, metal=1, emit=0, transp=0), -1)
+    t2 = api.make_triangle((-1000, 100, 1000), (1000, 100, 1000), (0, 100, -1000), (0, -1, 0), (1, 1, 1), 0, 0, 0, 0.0, 1.2)
+    sc = scenes.Scene("template", np.concatenate([t1, t2]), faces6, (1.0, list(range(6))), eye=(50.0, 50.0, 0.0), at=(0.0, 0.0, 0.0),
+                      focal=400.0, rotate=0.0, width=W, height=H, max_depth=2, n_diff=2, n_spec=2, bg=(0.0, 0.0, 0.0), seed=0x5EED)
+    O = load_into(binding.Oracle(), sc)
+    acc = np.zeros((H, W, 4), np.float32)
+    for i in range(1, frames + 1):
+        O.render_rows(i, acc, nthreads=16)
+        want = O.tonemap(acc, i).reshape(H, W, 3)
+        got = read_png(os.path.join(d, "out_%03d.png" % i))
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), "frame %d: %d bytes differ" % (i, (got != want).sum())
+    assert want.std() > 10 and (want.reshape(-1, 3).max(axis=1) > 0).mean() > 0.5
+
+
 def test_cli_contract_errors(tmp_path, native_libs):
     """Argument check and parse errors: printed, exit code as in src/main.cpp:4-16.  No GPU is touched before
     these errors are raised."""

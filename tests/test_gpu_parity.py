@@ -522,6 +522,49 @@ def test_multi_million_triangle_mesh_depth_8(libs):
     assert_bits_equal(full, rt2.accum(), "allowance 16")
 
 
+def test_ten_million_triangles_4k_depth_8(libs):
+    """The stress configuration at its named size: a displaced mesh of more than ten million triangles,
+    3840x2160, max_recursion_depth 8 (a gigabyte of nodes and triangle records: beyond the Infinity Cache).
+    Culled traversal == exhaustive traversal on every one of the 33 million primary samples; the frame's ray
+    count is the sum of its levels' and no pixel batch had to be rendered twice; two rows of the accumulator ==
+    the CPU restatement of the reference."""
+    sc = scenes.heightfield_scene(n_tris=10100000, width=3840, height=2160)
+    assert len(sc.tris) >= 10000000
+    sc.max_depth = 8
+    sc.n_diff = 1
+    sc.n_spec = 1
+    nodes = api.build_bvh(sc.tris)
+    rt = api.RayTracer(0)
+    rt.load_scene(sc, nodes)
+    ids0, tab0 = rt.primary_hits(0)
+    ids1, tab1 = rt.primary_hits(1)
+    assert ids0.size == 3840 * 2160 * 4
+    assert np.array_equal(ids0, ids1)
+    hit = ids0 >= 0
+    assert 0.2 < hit.mean() < 0.999
+    assert_bits_equal(tab0[hit], tab1[hit], "t/alpha/beta")
+    del ids1, tab1, tab0
+    rt.reset()
+    rt.render(1, 1)
+    st = rt.stats()
+    assert st["rays_per_level"][0] == 3840 * 2160 * 4 and st["rays"] == sum(st["rays_per_level"])
+    # an open scene: most paths leave after a bounce or two, a few go on (33.2 M, 11.5 M, 384 k, 27 k, 2.3 k, 202, ...)
+    assert all(st["rays_per_level"][lv] > 0 for lv in range(6)), st["rays_per_level"]
+    assert st["queue_retries"] == 0, st["queue_retries"]
+    assert st["rays_wave_traced"] > 0
+    full = rt.accum()
+    O = binding.Oracle()
+    load_into(O, sc, build=False)
+    O.set_nodes(nodes)
+    acc_o = np.zeros((sc.height, sc.width, 4), np.float32)
+    O.render_rows(1, acc_o, row0=1200, row1=1202, nthreads=16)
+    assert full[1200:1202, :, :3].any()
+    assert_bits_equal(acc_o[1200:1202, :, :3], full[1200:1202, :, :3], "rows 1200..1201 vs CPU")
+    # the second frame sizes its queues from the first one's populations and still needs no second try
+    rt.render(2, 1)
+    assert rt.stats()["queue_retries"] == 0
+
+
 def test_queue_history_overflow_is_rendered_again(libs):
     """Queues are sized from the ray populations of earlier frames.  History taken from one tile of sky makes
     the queues of the full image far too small: the device notices, stores nothing of such a batch, and the
