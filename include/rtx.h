@@ -187,6 +187,19 @@ int rtx_trace_rays_noalloc(rtx_scene* s, int mode, uint32_t n, const float* d_or
  * primary ray: out[height*width*4][4].  Tiles outside the scene's tile set are left untouched. */
 int rtx_sample_radiance(rtx_scene* s, uint32_t frame, float* host_out);
 
+/* Several GPUs in one process: the exchange step after the row loop that rtx_scene_set_tiles split
+ * (src/RayTracer.cpp:237; the reference's loop writes one shared accumulateImg, here every GPU holds its tile
+ * share in an image of its own).  scenes[r], r = 0..n-1, live on n different GPUs, have the same image size and
+ * hold the tile share (r, n) -- rtx_scene_set_tiles(scenes[r], r, n, -1).  The accumulator tiles of scenes
+ * 1..n-1 are packed on their GPUs, sent to scenes[0]'s GPU with RCCL (one ncclSend/ncclRecv pair per peer inside
+ * one group, i.e. one message per xGMI link, all at once) and written into scenes[0]'s accumulator, which then
+ * is the whole image for rtx_tonemap_read / rtx_accum_read.  The other accumulators are left as they are.
+ * Communicators are created on the first call (ncclCommInitAll over the scenes' devices) and kept for later
+ * calls with the same devices.  librccl.so is opened at the first call; a process that never calls this does
+ * not need it.  With n = 1 the single share is packed, sent to itself and unpacked (what a test on one GPU can
+ * exercise).  Blocks until the image is complete.  One thread at a time. */
+int rtx_gather_tiles(rtx_scene* const* scenes, int n);
+
 /* When enabled, traversal kernels count box and triangle tests (slower). */
 int rtx_scene_set_instrumented(rtx_scene* s, int enabled);
 int rtx_get_stats(rtx_scene* s, rtx_stats* out);

@@ -67,6 +67,7 @@ HIP_SYMBOLS = {
     "rtx_trace_rays": (_i, [_vp, _i, _u32, _fp, _fp, _ip, _fp]),
     "rtx_trace_rays_noalloc": (_i, [_vp, _i, _u32, _vp, _vp, _vp, _vp]),
     "rtx_sample_radiance": (_i, [_vp, _u32, _fp]),
+    "rtx_gather_tiles": (_i, [C.POINTER(_vp), _i]),
     "rtx_scene_set_instrumented": (_i, [_vp, _i]),
     "rtx_get_stats": (_i, [_vp, C.POINTER(Stats)]),
 }
@@ -201,6 +202,12 @@ def tonemap_table():
 
 def run_config(config_path, out_dir=".", n_devices=1):
     _chkh(host_lib().rtxh_run_config(os.fsencode(config_path), os.fsencode(out_dir), n_devices))
+
+
+def gather_tiles(tracers):
+    """rtx_gather_tiles: the tile shares of tracers[1:] (one GPU each) travel to tracers[0]'s accumulator over RCCL."""
+    arr = (_vp * len(tracers))(*[t.h for t in tracers])
+    _chk(hip_lib().rtx_gather_tiles(arr, len(tracers)))
 
 
 # ---- the device-side scene -----------------------------------------------------------------------

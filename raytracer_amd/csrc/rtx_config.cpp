@@ -331,6 +331,7 @@ struct HipApi {
 	RTX_FN(rtx_scene_set_tonemap_table)
 	RTX_FN(rtx_tonemap_read)
 	RTX_FN(rtx_get_stats)
+	RTX_FN(rtx_gather_tiles)
 #undef RTX_FN
 };
 
@@ -361,6 +362,7 @@ void bind_hip(HipApi& api) {
 	RTX_FN(rtx_scene_set_tonemap_table)
 	RTX_FN(rtx_tonemap_read)
 	RTX_FN(rtx_get_stats)
+	RTX_FN(rtx_gather_tiles)
 #undef RTX_FN
 }
 
@@ -613,8 +615,6 @@ void HostRayTracer::render(const std::string& outDir, int nDevices) {
 
 	struct Dev {
 		rtx_scene* scene = nullptr;
-		std::vector<float> accum;   // host tone map only
-		std::vector<uint8_t> rgb;   // device tone map: the whole image, this device's tiles valid
 	};
 	std::vector<Dev> devs(nDevices);
 	struct Cleanup {
@@ -647,12 +647,7 @@ void HostRayTracer::render(const std::string& outDir, int nDevices) {
 		chk(hip.rtx_scene_set_bvh(s, nodes.data(), (uint32_t)nodes.size()));
 		chk(hip.rtx_scene_set_tables(s, ct.data(), st.data(), gt.data()));
 		chk(hip.rtx_scene_set_tiles(s, d, nDevices, -1));
-		if (deviceToneMap) {
-			chk(hip.rtx_scene_set_tonemap_table(s, toneBits.data(), toneVal.data(), toneN, toneSpecial[0], toneSpecial[1]));
-			devs[d].rgb.assign((size_t)width * height * 3, 0);
-		}
-		else
-			devs[d].accum.assign((size_t)width * height * 4, 0.0f);
+		if (deviceToneMap && d == 0) chk(hip.rtx_scene_set_tonemap_table(s, toneBits.data(), toneVal.data(), toneN, toneSpecial[0], toneSpecial[1]));
 	}
 
 	// Images are encoded and written by a second thread while the next frame renders; the frame's line on
@@ -704,42 +699,37 @@ void HostRayTracer::render(const std::string& outDir, int nDevices) {
 		}
 	} joinWriter{mu, cv, done, writer};
 
+	// Every device renders its tile share of frame i on a thread of its own; the shares then travel to device 0
+	// over RCCL (one message per peer, each over its own xGMI link, rtx_gather_tiles) and device 0 alone hands
+	// the image back: 8-bit from its tone map, or the accumulator if the table could not be built.
 	std::vector<float> accumulateImg;
 	if (!deviceToneMap) accumulateImg.assign((size_t)width * height * 4, 0.0f);
-	const int tilesX = (width + TILE - 1) / TILE;
+	std::vector<rtx_scene*> scenes(nDevices);
+	for (int d = 0; d < nDevices; ++d) scenes[d] = devs[d].scene;
 	for (int i = 1; i <= renderNum; ++i) {
 		auto time1 = std::chrono::system_clock::now();
 		std::vector<std::string> errors(nDevices);
-		std::vector<std::thread> workers;
-		for (int d = 0; d < nDevices; ++d)
-			workers.emplace_back([&, d] {
-				// rtx_last_error is per thread: fetch it on the thread that made the call
-				int rc = hip.rtx_render_frames(devs[d].scene, (uint32_t)i, 1);
-				if (rc >= 0)
-					rc = deviceToneMap ? hip.rtx_tonemap_read(devs[d].scene, i, devs[d].rgb.data())
-									   : hip.rtx_accum_read(devs[d].scene, devs[d].accum.data());
-				if (rc < 0) errors[d] = hip.rtx_last_error();
-			});
-		for (auto& w : workers) w.join();
+		if (nDevices == 1) {
+			if (hip.rtx_render_frames(scenes[0], (uint32_t)i, 1) < 0) errors[0] = hip.rtx_last_error();
+		}
+		else {
+			std::vector<std::thread> workers;
+			for (int d = 0; d < nDevices; ++d)
+				workers.emplace_back([&, d] {
+					// rtx_last_error is per thread: fetch it on the thread that made the call
+					if (hip.rtx_render_frames(scenes[d], (uint32_t)i, 1) < 0) errors[d] = hip.rtx_last_error();
+				});
+			for (auto& w : workers) w.join();
+		}
 		for (const auto& e : errors)
 			if (!e.empty()) throw std::runtime_error("GPU path: " + e);
-		// each tile is owned by device (tile index % nDevices)
+		if (nDevices > 1) chk(hip.rtx_gather_tiles(scenes.data(), nDevices));
 		std::vector<uint8_t> outputBuffer((size_t)width * height * 3);
-		const size_t px = deviceToneMap ? 3 : 4;  // units per pixel of what the devices handed back
-		if (nDevices == 1) {
-			if (deviceToneMap) outputBuffer = devs[0].rgb;
-			else accumulateImg = devs[0].accum;
+		if (deviceToneMap) chk(hip.rtx_tonemap_read(scenes[0], i, outputBuffer.data()));
+		else {
+			chk(hip.rtx_accum_read(scenes[0], accumulateImg.data()));
+			tonemap(accumulateImg.data(), i, (size_t)width * height, outputBuffer.data());
 		}
-		else
-			for (int y = 0; y < height; ++y)
-				for (int x0 = 0; x0 < width; x0 += TILE) {
-					const int owner = ((y / TILE) * tilesX + x0 / TILE) % nDevices;
-					const size_t o = ((size_t)y * width + x0) * px;
-					const size_t n = (size_t)std::min(TILE, width - x0) * px;
-					if (deviceToneMap) std::memcpy(&outputBuffer[o], &devs[owner].rgb[o], n);
-					else std::memcpy(&accumulateImg[o], &devs[owner].accum[o], n * sizeof(float));
-				}
-		if (!deviceToneMap) tonemap(accumulateImg.data(), i, (size_t)width * height, outputBuffer.data());
 		auto time2 = std::chrono::system_clock::now();  // the reference's interval covers the tone map too (:235-261)
 		{
 			std::unique_lock<std::mutex> lk(mu);

@@ -55,7 +55,7 @@ struct DevScene {
 // Bits of DevScene::fault.  An index is checked wherever it comes out of a queue record and is about to address
 // scene data: a record nobody wrote must end in an error code, never in an access outside the arrays.
 constexpr unsigned FAULT_HIT_RANK = 1u, FAULT_TEX_ID = 2u, FAULT_CHILD_SLOT = 4u, FAULT_NODE = 8u, FAULT_LEAF = 16u,
-				   FAULT_STACK = 32u, FAULT_LONG_ROUNDS = 64u;
+				   FAULT_STACK = 32u, FAULT_LONG_ROUNDS = 64u, FAULT_LIST_ENTRY = 128u;
 
 // ------------------------------------------------------------------------------------------------
 // Small device helpers.  dot4 is Eigen's reduction order with the (zero) w lane kept as "+ 0.0f".

@@ -495,6 +495,29 @@ __global__ __launch_bounds__(256) void k_tonemap(const float4* __restrict__ accu
 	}
 }
 
+// Exchange of tile accumulators between GPUs.  A share is the tiles first, first + stride, ...; slot k of the packed
+// array holds tile first + k * stride as TILE x TILE float4 in row-major order (pixels beyond the image: zero).
+// k_pack_tiles copies a share out of an image, k_unpack_tiles copies one into an image.  One thread per pixel slot.
+__global__ __launch_bounds__(256) void k_pack_tiles(const float4* __restrict__ accum, int width, int height, int tilesX, int first,
+													int stride, int slots, float4* __restrict__ packed) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= slots * TILE * TILE) return;
+	const int slot = i / (TILE * TILE), p = i - slot * (TILE * TILE);
+	const int tile = first + slot * stride;
+	const int x = (tile % tilesX) * TILE + (p % TILE), y = (tile / tilesX) * TILE + p / TILE;
+	packed[i] = (x < width && y < height) ? accum[(size_t)y * width + x] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+__global__ __launch_bounds__(256) void k_unpack_tiles(float4* __restrict__ accum, int width, int height, int tilesX, int first,
+													  int stride, int slots, const float4* __restrict__ packed) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= slots * TILE * TILE) return;
+	const int slot = i / (TILE * TILE), p = i - slot * (TILE * TILE);
+	const int tile = first + slot * stride;
+	const int x = (tile % tilesX) * TILE + (p % TILE), y = (tile / tilesX) * TILE + p / TILE;
+	if (x < width && y < height) accum[(size_t)y * width + x] = packed[i];
+}
+
 // Per-sample radiance export (rtx_sample_radiance): out[(y*W+x)*4+sub] = A[j].
 __global__ __launch_bounds__(256) void k_export_samples(DevScene sc, Batch b, const float4* __restrict__ A,
 														float4* __restrict__ out, const unsigned* __restrict__ counts) {

@@ -127,9 +127,10 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 														  const unsigned* __restrict__ nDev) {
 	// the queue length may live on the device (written by the previous level's shade kernel); n is then the
 	// capacity of the arrays
+	const int capN = n;  // capacity of the ray arrays: what an entry of the list may index
 	if (nDev) n = (int)min(*nDev, (unsigned)n);
 	// with a list: the rays to trace are list[0 .. *listCount), the ones the wide traversal set aside
-	if (list) n = (int)*listCount;
+	if (list) n = (int)min(*listCount, (unsigned)capN);
 	// A short queue is cut into smaller chunks, so that every wave of the grid has about three to take: with
 	// chunks of the full size a queue of a million rays would occupy two waves in three and the launch would
 	// last as long as one wave needs for its whole chunk.
@@ -192,9 +193,16 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 				if (!busy && slot < take) {
 					j = cnext + slot;
 					if (list) j = list[j];
-					float4 O = rayO[j];
-					float4 D = rayD[j];
-					if (D.w != 0.0f) {
+					const bool inRange = (unsigned)j < (unsigned)capN;
+					float4 O = make_float4(0.0f, 0.0f, 0.0f, 0.0f), D = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+					if (inRange) {
+						O = rayO[j];
+						D = rayD[j];
+					}
+					if (!inRange) {
+						atomicOr(sc.fault, FAULT_LIST_ENTRY);  // a list entry that is no ray of this queue: skipped, reported to the host
+					}
+					else if (D.w != 0.0f) {
 						// not to be traced: 1 = no ray at all (refraction under total internal reflection),
 						// 2 = a ray of the last level whose value is zero whether it hits or not
 						put_hit<ANYHIT>(hits, j, D.w == 2.0f ? -3 : -2, FLT_MAX, 0.0f, 0.0f);
@@ -698,7 +706,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_long(DevScene sc, const
 															  const float4* __restrict__ rayD, float4* __restrict__ hits,
 															  const int* __restrict__ list, const unsigned* __restrict__ listCount,
 															  int* __restrict__ unsafeList,
-															  unsigned* __restrict__ unsafeCount, unsigned long long* __restrict__ stats) {
+															  unsigned* __restrict__ unsafeCount, unsigned long long* __restrict__ stats, int capN) {
 	__shared__ int sStack[TRACE_THREADS / 64][LONG_STACK];
 	__shared__ int sLeaf[TRACE_THREADS / 64][LONG_LEAVES];
 	const unsigned lane = threadIdx.x & 63u;
@@ -706,7 +714,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_long(DevScene sc, const
 	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
 	int* stk = sStack[w];
 	int* lf = sLeaf[w];
-	const unsigned count = *listCount;
+	const unsigned count = min(*listCount, (unsigned)capN);  // capN: capacity of the ray arrays and of the list
 	unsigned nodeVisits = 0, leafFetches = 0, boxTests = 0, triTests = 0;  // wave-level, kept uniform
 	// Everything a wave does here is uniform over its lanes, and the code keeps it visibly so: no statement is
 	// guarded by "lane == 0" (all lanes store the same value to the same place instead).  Lanes that skip such a
@@ -714,6 +722,10 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_long(DevScene sc, const
 	const unsigned nWaves = gridDim.x * (TRACE_THREADS / 64);
 	for (unsigned idx = blockIdx.x * (TRACE_THREADS / 64) + (unsigned)w; idx < count; idx += nWaves) {
 		const int j = list[idx];
+		if ((unsigned)j >= (unsigned)capN) {
+			atomicOr(sc.fault, FAULT_LIST_ENTRY);  // not a ray of this queue (uniform over the wave): skipped, reported to the host
+			continue;
+		}
 		const float4 O = rayO[j], D = rayD[j];
 		// the ray was being walked by k_trace_wide, so its reciprocals are finite or infinite, never huge
 		RaySlab r;

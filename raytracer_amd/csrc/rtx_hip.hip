@@ -37,6 +37,8 @@
 // the C ABI), rtx_wide.h (construction of the traversal tree).
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is opened when rtx_gather_tiles is first called
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cfloat>
@@ -196,10 +198,15 @@ struct rtx_scene {
 	int stackNeed = 32;  // deepest interior node: the traversal pushes at most once per interior level
 	int wideStackNeed = 52;  // wide traversal: entries waiting when every child of every node on a path is hit
 	int wideStackCap = 24;   // RTX_WIDE_STACK: 16 or 24
-	// largest number of rays per primary sample seen at each level so far (0: nothing seen yet)
+	// Rays per primary sample at each level: popRatio the largest seen so far (0: nothing seen yet), capRatio what
+	// the queues of the next batch are sized for.  Levels up to capKnown rest on counts a batch has reported, the
+	// deeper ones on a guess.
 	double popRatio[17] = {0};
-	bool haveHistory = false;
-	bool worstCaseQueues = false;  // RTX_WORST_CASE_QUEUES=1: never size queues from history
+	double capRatio[17] = {0};
+	int capKnown = 0;
+	bool haveCaps = false;
+	bool syncLaunches = false;     // RTX_SYNC_LAUNCHES=1: wait for every kernel and name the one that fails (debugging)
+	bool worstCaseQueues = false;  // RTX_WORST_CASE_QUEUES=1: queues for the theoretical worst case, always
 	bool wideOk = false;     // the tree satisfies what k_trace_wide relies on
 	bool forceBinary = false;  // RTX_TRACE_BINARY=1: binary-tree kernel only (for comparisons)
 	uint32_t numWide = 0;
@@ -216,6 +223,8 @@ struct rtx_scene {
 	DevBuf<float4> dAccumOwn;
 	float4* dAccum = nullptr;  // own or external
 	bool texDirty = true;
+	DevBuf<float4> dTilePack;   // rtx_gather_tiles: this scene's share, packed (the share that is sent)
+	DevBuf<float4> dTileRecv;   // rtx_gather_tiles, scene 0: the shares of the others as they arrive
 	DevBuf<uint8_t> arena;
 	DevBuf<unsigned> dCounts;           // 8 per level
 	DevBuf<unsigned long long> dStats;  // node tests, tri tests
@@ -230,7 +239,7 @@ struct rtx_scene {
 	~rtx_scene() {
 		(void)hipSetDevice(device);
 		dPairs.release(); dWide.release(); dTriHit.release(); dTriShade.release(); dToneBits.release(); dToneVal.release(); dRgb8.release(); dTexels.release(); dTexDesc.release();
-		dTables.release(); dAccumOwn.release(); arena.release(); dCounts.release(); dStats.release();
+		dTables.release(); dAccumOwn.release(); dTilePack.release(); dTileRecv.release(); arena.release(); dCounts.release(); dStats.release();
 		if (hCounts) (void)hipHostFree(hCounts);
 		if (hStats) (void)hipHostFree(hStats);
 		for (auto& e : events) {
@@ -254,6 +263,20 @@ int check_fault(unsigned bits) {
 	return fail(RTX_ERR_DEVICE, "device consistency check failed (fault bits " + std::to_string(bits) +
 									"): a queue record held an index outside the scene; the image of this call is not valid");
 }
+
+// After every kernel launch: the launch error, and with RTX_SYNC_LAUNCHES=1 (debugging) the kernel's own
+// completion, reported under the kernel's name.
+int launched(rtx_scene* s, const char* kernel) {
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess && s->syncLaunches) e = hipStreamSynchronize(s->stream);
+	if (e != hipSuccess) return fail(RTX_ERR_DEVICE, std::string(kernel) + ": " + hipGetErrorString(e));
+	return RTX_OK;
+}
+#define RTX_LAUNCHED(kernel)                \
+	do {                                    \
+		const int rcl_ = launched(s, kernel); \
+		if (rcl_) return rcl_;              \
+	} while (0)
 
 int num_tiles(const rtx_scene* s) {
 	int tx = (s->width + TILE - 1) / TILE, ty = (s->height + TILE - 1) / TILE;
@@ -362,10 +385,6 @@ int ensure_ready(rtx_scene* s, bool needCamera) {
 	return RTX_OK;
 }
 
-// Queue bytes.  Persistent per path node: A (16) + B (16) + C (16); transient, two ping-pong sets sized
-// for the widest level: origin (16) + direction (16) + hit (16).
-constexpr size_t NODE_BYTES = 24, RAY_BYTES = 48;
-
 constexpr size_t NO_EVENT = ~(size_t)0;
 
 int take_event(rtx_scene* s, hipEvent_t& e) {
@@ -471,7 +490,7 @@ int launch_exact_t(rtx_scene* s, const DevScene& d, const float4* ro, const floa
 		if (st) RTX_LAUNCH(32, true); else RTX_LAUNCH(32, false);
 	}
 #undef RTX_LAUNCH
-	HIPCHK(hipGetLastError());
+	RTX_LAUNCHED("k_trace");
 	return RTX_OK;
 }
 
@@ -496,23 +515,23 @@ int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float
 		if (st) RTX_LAUNCH(24, true); else RTX_LAUNCH(24, false);
 	}
 #undef RTX_LAUNCH
-	HIPCHK(hipGetLastError());
+	RTX_LAUNCHED("k_trace_wide");
 	return RTX_OK;
 }
 
 // The wave-per-ray kernel over the rays the wide traversal found too long for one lane; the count lives on the
 // device, so the grid is a fixed small one.
 template <bool ANYHIT>
-int launch_long_t(rtx_scene* s, const DevScene& d, const float4* ro, const float4* rd, float4* hits, const int* longList,
+int launch_long_t(rtx_scene* s, const DevScene& d, const float4* ro, const float4* rd, float4* hits, int n, const int* longList,
 				  const unsigned* longCount, int* unsafeList, unsigned* unsafeCount) {
 	dim3 grid(std::max(1, s->numCUs * s->longBlocksPerCU)), block(TRACE_THREADS);
 	if (s->instrumented)
 		hipLaunchKernelGGL((k_trace_long<ANYHIT, true>), grid, block, 0, s->stream, d, ro, rd, hits, longList, longCount, unsafeList,
-						   unsafeCount, s->dStats.p);
+						   unsafeCount, s->dStats.p, n);
 	else
 		hipLaunchKernelGGL((k_trace_long<ANYHIT, false>), grid, block, 0, s->stream, d, ro, rd, hits, longList, longCount, unsafeList,
-						   unsafeCount, s->dStats.p);
-	HIPCHK(hipGetLastError());
+						   unsafeCount, s->dStats.p, n);
+	RTX_LAUNCHED("k_trace_long");
 	return RTX_OK;
 }
 
@@ -535,14 +554,14 @@ int launch_trace(rtx_scene* s, const DevScene& d, bool anyhit, bool exhaustive, 
 	else if (anyhit) {
 		rc = launch_wide_t<true>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, unsafeList, cnt + UNSAFE_SLOT, nDev, unsafeList + n, cnt + LONG_SLOT);
 		if (rc == RTX_OK && s->longVisits != INT_MAX)
-			rc = launch_long_t<true>(s, d, ro, rd, hits, unsafeList + n, cnt + LONG_SLOT, unsafeList, cnt + UNSAFE_SLOT);
+			rc = launch_long_t<true>(s, d, ro, rd, hits, n, unsafeList + n, cnt + LONG_SLOT, unsafeList, cnt + UNSAFE_SLOT);
 		if (rc == RTX_OK)
 			rc = launch_exact_t<true, false>(s, d, ro, rd, hits, n, cnt + WORK2_SLOT, unsafeList, cnt + UNSAFE_SLOT, nullptr);
 	}
 	else {
 		rc = launch_wide_t<false>(s, d, ro, rd, hits, n, cnt + WORK_SLOT, unsafeList, cnt + UNSAFE_SLOT, nDev, unsafeList + n, cnt + LONG_SLOT);
 		if (rc == RTX_OK && s->longVisits != INT_MAX)
-			rc = launch_long_t<false>(s, d, ro, rd, hits, unsafeList + n, cnt + LONG_SLOT, unsafeList, cnt + UNSAFE_SLOT);
+			rc = launch_long_t<false>(s, d, ro, rd, hits, n, unsafeList + n, cnt + LONG_SLOT, unsafeList, cnt + UNSAFE_SLOT);
 		if (rc == RTX_OK)
 			rc = launch_exact_t<false, false>(s, d, ro, rd, hits, n, cnt + WORK2_SLOT, unsafeList, cnt + UNSAFE_SLOT, nullptr);
 	}
@@ -573,16 +592,35 @@ struct Bump {
 	}
 };
 
-// Rays per primary sample each level's queue is sized for.  Worst case: every node spawns its maximum at every
-// level.  With history: 1.3 times the most seen so far plus a little, capped by the worst case; a batch that
-// outgrows that is detected on the device, left out of the image and rendered again with worst-case queues.
-void level_ratios(const rtx_scene* s, bool useHistory, int levels, double* r) {
-	const double bmax = (double)std::max(s->nSpec + s->nDiff, s->nSpec + 1);
-	double worst = 1.0;
-	for (int lv = 0; lv <= levels; ++lv) {
-		r[lv] = (useHistory && lv > 0) ? std::min(worst, s->popRatio[lv] * 1.3 + 1.0 / 64.0) : worst;
-		worst *= bmax;
+// Most rays a node can spawn, and the rays per primary sample at level lv if every node did (a double: 65^15
+// does not fit an integer).
+double branch_max(const rtx_scene* s) { return (double)std::max(s->nSpec + s->nDiff, s->nSpec + 1); }
+double worst_ratio(const rtx_scene* s, int lv) { return std::pow(branch_max(s), (double)lv); }
+
+// Queue capacities before anything has been seen: the worst case while that is small (the first frame then cannot
+// overflow), a bounded guess where it is not.  A batch that outgrows its queues says so (the device keeps
+// counting what was asked for) and is rendered again with larger ones; see grow_caps.
+void reset_caps(rtx_scene* s) {
+	const double guess = std::max(32.0, branch_max(s));
+	for (int lv = 0; lv <= MAX_DEPTH + 1; ++lv) {
+		s->popRatio[lv] = 0.0;
+		s->capRatio[lv] = s->worstCaseQueues ? worst_ratio(s, lv) : std::min(worst_ratio(s, lv), guess);
 	}
+	s->capKnown = 0;
+	s->haveCaps = true;
+}
+
+// Bytes of the work arena per primary sample for the given level capacities: a 24-byte node record for every
+// level but the last (the primary-hit export, levels == 0, keeps one), and two ping-pong ray sets plus the two
+// ray lists, sized for the widest level.
+constexpr size_t NODE_BYTES = 24, RAY_BYTES = 48;
+double bytes_per_sample(const double* ratio, int levels) {
+	double sum = 0.0, widest = 1.0;
+	for (int lv = 0; lv <= levels; ++lv) {
+		if (lv < levels || levels == 0) sum += ratio[lv];
+		widest = std::max(widest, ratio[lv]);
+	}
+	return sum * NODE_BYTES + widest * (2.0 * RAY_BYTES + 8.0);
 }
 
 struct RenderTarget {
@@ -596,55 +634,86 @@ struct RenderTarget {
 // Renders the 4x4-pixel blocks [gBegin, gEnd) in as few pixel batches as the arena allows.  Blocks are numbered
 // over the frames of the call first (`frame` is the frame of block 0), then over the scene's tile share
 // (blocksPerFrame of them), so a batch may span frames.
-int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTarget& tg, long long gBegin, long long gEnd,
-				 bool useHistory) {
+int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTarget& tg, long long gBegin, long long gEnd) {
 	const long long blocksPerFrame = (long long)tile_slots(s) * BLOCKS_PER_TILE;
 	const int mode = tg.mode;
 	const int levels = (mode == 2) ? 0 : s->maxDepth;
-	double ratio[MAX_DEPTH + 2];
-	level_ratios(s, useHistory, levels, ratio);
-	double sumRatio = 0.0, maxRatio = 0.0;
-	for (int lv = 0; lv <= levels; ++lv) {
-		// the last level keeps no node records (its values are formed inside the gather of the level above);
-		// levels == 0 is the primary-hit export, which keeps none at all
-		if (lv < levels) sumRatio += ratio[lv];
-		maxRatio = std::max(maxRatio, ratio[lv]);
-	}
-	// per sample: A and B of those levels; two ping-pong ray sets and the two ray lists (set aside, long) sized for the widest level
-	const double perSample = (mode == 2) ? (double)(NODE_BYTES + 2 * RAY_BYTES + 8) : sumRatio * NODE_BYTES + maxRatio * (2.0 * RAY_BYTES + 8.0);
+	if (!s->haveCaps) reset_caps(s);
 	const double fixedBytes = (double)(MAX_DEPTH + 8) * 4096 + (double)(levels + 1) * 1024.0 * NODE_BYTES + 1024.0 * (2.0 * RAY_BYTES + 8.0) + 65536.0;
 	// Frames are merged into one batch up to about the samples of one 1080p frame (whole frames only; a share
 	// that is larger than that is rendered frame by frame as the arena allows): enough to fill the queues of a
 	// small tile share without multiplying the arena of a big one.
 	const long long mergeBlocks = std::max(blocksPerFrame, (s->mergeBlocks / blocksPerFrame) * blocksPerFrame);
-	const long long totalBlocks = std::min(gEnd - gBegin, mergeBlocks);
 
 	size_t freeB = 0, totalB = 0;
 	HIPCHK(hipMemGetInfo(&freeB, &totalB));
 	// Default budget: 60 % of what is free, at most 64 GiB.  Each batch costs one synchronisation plus, per
 	// level, the latency of its longest ray, so bigger batches are better; allocating and mapping hundreds of GB
-	// costs seconds, so the arena is not grown beyond that.
-	size_t budget = s->arenaLimit ? (size_t)s->arenaLimit
-								  : std::min<size_t>((size_t)((double)(freeB + s->arena.n) * 0.6), (size_t)64 << 30);
-	const double needAll = perSample * (double)totalBlocks * SAMPLES_PER_BLOCK + fixedBytes;
-	size_t want = (size_t)std::min((double)budget, needAll);
-	// an arena that is at least nearly as big as wanted is used as it is rather than reallocated
-	if (s->arena.n && (double)s->arena.n >= 0.9 * (double)want) want = std::max(want, s->arena.n);
-	if (s->arenaLimit && want > (size_t)s->arenaLimit) want = (size_t)s->arenaLimit;
-	long long blocksPerBatch = (long long)(((double)want - fixedBytes) / (perSample * SAMPLES_PER_BLOCK));
-	if (blocksPerBatch < 1) {
-		blocksPerBatch = 1;
-		want = (size_t)(perSample * SAMPLES_PER_BLOCK + fixedBytes);
-	}
-	if (blocksPerBatch > totalBlocks) blocksPerBatch = totalBlocks;
-	// keep ray indices inside int32
-	const long long maxBlocksInt = (long long)(0x7FFFF000ll / SAMPLES_PER_BLOCK);
-	if ((double)blocksPerBatch * maxRatio > (double)maxBlocksInt) blocksPerBatch = std::max<long long>(1, (long long)((double)maxBlocksInt / maxRatio));
-	int rc = ensure_arena(s, want);
-	if (rc) return rc;
+	// costs seconds, so the arena is not grown beyond that.  The arena never exceeds the budget.
+	const size_t budget = s->arenaLimit ? (size_t)s->arenaLimit
+										: std::min<size_t>((size_t)((double)(freeB + s->arena.n) * 0.6), (size_t)64 << 30);
+	auto over_budget = [&](double needBytes) {
+		return fail(RTX_ERR_MEMORY, "the ray queues of one 4x4-pixel block need " + std::to_string((unsigned long long)(needBytes / 1048576.0) + 1) +
+										" MiB at the ray populations seen so far (max_depth " + std::to_string(s->maxDepth) + ", " +
+										std::to_string(s->nSpec) + " specular + " + std::to_string(s->nDiff) + " diffuse rays per hit), beyond the work-arena limit of " +
+										std::to_string((unsigned long long)(budget >> 20)) + " MiB (" +
+										(s->arenaLimit ? "rtx_scene_set_arena_bytes" : "the default: 60 % of free device memory, at most 64 GiB") + ")");
+	};
 
-	for (long long g0 = gBegin; g0 < gEnd; g0 += blocksPerBatch) {
-		const long long nb = std::min(blocksPerBatch, gEnd - g0);
+	int attempts = 0;  // tries of the batch that starts at g0
+	int rc = RTX_OK;
+	for (long long g0 = gBegin; g0 < gEnd;) {
+		// ---- plan this batch from the capacities as they stand now (an overflow or a first success changes them)
+		double ratio[MAX_DEPTH + 2];
+		for (int lv = 0; lv <= levels; ++lv) ratio[lv] = lv == 0 ? 1.0 : s->capRatio[lv];
+		double perSample = bytes_per_sample(ratio, levels);
+		if (perSample * SAMPLES_PER_BLOCK + fixedBytes > (double)budget) {
+			// Not even one pixel block fits.  Levels beyond capKnown are guesses: they share what the known levels
+			// leave of the budget, equally, and the device reports which of them was too small.
+			const int known = std::min(s->capKnown, levels);
+			double knownNodes = 0.0, knownWidest = 1.0;
+			int guessedWithNodes = 0;
+			for (int lv = 0; lv <= levels; ++lv) {
+				if (lv <= known) {
+					if (lv < levels) knownNodes += ratio[lv];
+					knownWidest = std::max(knownWidest, ratio[lv]);
+				}
+				else if (lv < levels) guessedWithNodes++;
+			}
+			const double avail = ((double)budget - fixedBytes) / SAMPLES_PER_BLOCK - knownNodes * NODE_BYTES;
+			const double rayBytes = 2.0 * RAY_BYTES + 8.0;
+			if (known >= levels || avail <= knownWidest * rayBytes) return over_budget(perSample * SAMPLES_PER_BLOCK + fixedBytes);
+			// guessed levels all get c rays per sample: c is the widest level if it exceeds the known ones
+			double c = avail / (guessedWithNodes * (double)NODE_BYTES + rayBytes);
+			if (c < knownWidest) c = guessedWithNodes ? (avail - knownWidest * rayBytes) / (guessedWithNodes * (double)NODE_BYTES) : knownWidest;
+			c *= 0.999;
+			if (!(c > 0.0)) return over_budget(perSample * SAMPLES_PER_BLOCK + fixedBytes);
+			for (int lv = known + 1; lv <= levels; ++lv) ratio[lv] = std::min(ratio[lv], c);
+			perSample = bytes_per_sample(ratio, levels);
+		}
+		double maxRatio = 1.0;
+		for (int lv = 0; lv <= levels; ++lv) maxRatio = std::max(maxRatio, ratio[lv]);
+		const long long totalBlocks = std::min(gEnd - g0, mergeBlocks);
+		const double needAll = perSample * (double)totalBlocks * SAMPLES_PER_BLOCK + fixedBytes;
+		// The arena's size is kept a multiple of 4 KiB (rounded down: never beyond the budget), because the ray sets
+		// are carved from its top end: a size that is not a multiple of 16 would put every float4 of them at a
+		// misaligned address, and the scalar loads of the wave-per-ray kernel would read the wrong words.
+		size_t want = (size_t)std::min((double)budget, needAll + 4096.0) & ~(size_t)4095;
+		// an arena that is at least nearly as big as wanted is used as it is rather than reallocated
+		if (s->arena.n && (double)s->arena.n >= 0.9 * (double)want && s->arena.n <= budget) want = std::max(want, s->arena.n);
+		long long blocksPerBatch = (long long)(((double)want - fixedBytes) / (perSample * SAMPLES_PER_BLOCK));
+		if (blocksPerBatch < 1) return over_budget(perSample * SAMPLES_PER_BLOCK + fixedBytes);
+		if (blocksPerBatch > totalBlocks) blocksPerBatch = totalBlocks;
+		// keep ray indices inside int32
+		const long long maxBlocksInt = (long long)(0x7FFFF000ll / SAMPLES_PER_BLOCK);
+		if ((double)blocksPerBatch * maxRatio > (double)maxBlocksInt) {
+			blocksPerBatch = (long long)((double)maxBlocksInt / maxRatio);
+			if (blocksPerBatch < 1) return fail(RTX_ERR_MEMORY, "one 4x4-pixel block spawns more than 2^31 rays at one level: beyond the queue index range");
+		}
+		rc = ensure_arena(s, want);
+		if (rc) return rc;
+
+		const long long nb = blocksPerBatch;
 		Batch b;
 		b.g0 = (int)g0;
 		b.nSamples = (int)(nb * SAMPLES_PER_BLOCK);
@@ -657,23 +726,21 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 		// capacities of the levels of this batch
 		size_t cap[MAX_DEPTH + 2];
 		size_t widestCap = (size_t)b.nSamples;
-		{
-			size_t worst = (size_t)b.nSamples;
-			const size_t bmax = (size_t)std::max(s->nSpec + s->nDiff, s->nSpec + 1);
-			for (int lv = 0; lv <= levels; ++lv) {
-				cap[lv] = lv == 0 ? worst : std::min(worst, (size_t)std::ceil((double)b.nSamples * ratio[lv]) + 1024);
-				widestCap = std::max(widestCap, cap[lv]);
-				worst *= bmax;
-			}
-			cap[levels + 1] = 0;
+		for (int lv = 0; lv <= levels; ++lv) {
+			const double worst = (double)b.nSamples * worst_ratio(s, lv);
+			const double wanted = std::ceil((double)b.nSamples * ratio[lv]) + 1024.0;
+			cap[lv] = lv == 0 ? (size_t)b.nSamples : (size_t)std::min(worst, wanted);
+			widestCap = std::max(widestCap, cap[lv]);
 		}
+		cap[levels + 1] = 0;
 
 		// arena carve-up: transient ray sets at the top, node arrays bump-allocated from the bottom
 		const size_t setBytes = ((widestCap * 16 + 255) & ~(size_t)255);
 		const size_t listBytes = ((widestCap * 8 + 255) & ~(size_t)255);  // set-aside list + list of long rays
-		Bump bump{s->arena.p, s->arena.n, 0, s->arena.n};
+		Bump bump{s->arena.p, s->arena.n & ~(size_t)255, 0, 0};
 		if (6 * setBytes + listBytes > bump.cap) return fail(RTX_ERR_MEMORY, "work arena too small for one pixel block");
-		bump.hi = bump.cap - 6 * setBytes - listBytes;
+		bump.hi = bump.cap - 6 * setBytes - listBytes;  // a multiple of 256 like every term
+		if (((uintptr_t)bump.base | bump.hi) & 255) return fail(RTX_ERR_DEVICE, "work arena is not 256-byte aligned");
 		int* unsafeList = (int*)(bump.base + bump.hi + 6 * setBytes);
 		float4* rayO[2] = {(float4*)(bump.base + bump.hi), (float4*)(bump.base + bump.hi + 3 * setBytes)};
 		float4* rayD[2] = {(float4*)(bump.base + bump.hi + setBytes), (float4*)(bump.base + bump.hi + 4 * setBytes)};
@@ -684,7 +751,7 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 		rc = begin_event(s, 1, ev);
 		if (rc) return rc;
 		hipLaunchKernelGGL(k_raygen, dim3((b.nSamples + 255) / 256), dim3(256), 0, s->stream, d, b, rayO[0], rayD[0]);
-		HIPCHK(hipGetLastError());
+		RTX_LAUNCHED("k_raygen");
 		rc = end_event(s, ev);
 		if (rc) return rc;
 
@@ -692,11 +759,12 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 			rc = launch_trace(s, d, false, tg.hitMode == 1, rayO[0], rayD[0], hit[0], b.nSamples, s->dCounts.p, unsafeList);
 			if (rc) return rc;
 			hipLaunchKernelGGL(k_export_hits, dim3((b.nSamples + 255) / 256), dim3(256), 0, s->stream, d, b, hit[0], tg.dIds, tg.dTab);
-			HIPCHK(hipGetLastError());
+			RTX_LAUNCHED("k_export_hits");
 			HIPCHK(hipMemcpyAsync(s->hCounts + FAULT_WORD, s->dCounts.p + FAULT_WORD, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
 			HIPCHK(hipStreamSynchronize(s->stream));
 			rc = check_fault(s->hCounts[FAULT_WORD]);
 			if (rc) return rc;
+			g0 += nb;
 			continue;
 		}
 
@@ -725,7 +793,7 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 			hipLaunchKernelGGL(k_shade, dim3((unsigned)std::min<size_t>((n + SHADE_THREADS - 1) / SHADE_THREADS, (size_t)s->numCUs * 4)), dim3(SHADE_THREADS), 0, s->stream, d, lv,
 							   rayO[cur], rayD[cur], hit[cur], (int)n, A[lv], B[lv], rayO[nxt], rayD[nxt], cnt, (unsigned)cap[lv + 1],
 							   nDev);
-			HIPCHK(hipGetLastError());
+			RTX_LAUNCHED("k_shade");
 			rc = end_event(s, ev);
 			if (rc) return rc;
 		}
@@ -743,7 +811,7 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 			else
 				hipLaunchKernelGGL(k_gather<false>, grid, dim3(256), 0, s->stream, d, (int)cap[lv], A[lv], B[lv], (const float4*)A[lv + 1],
 								   (const int*)nullptr, (const float4*)nullptr, (unsigned)cap[lv + 1], (unsigned*)nullptr, nDev);
-			HIPCHK(hipGetLastError());
+			RTX_LAUNCHED("k_gather");
 		}
 		if (mode == 0) {
 			// one launch per frame the batch touches, in frame order
@@ -759,7 +827,7 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 		}
 		else
 			hipLaunchKernelGGL(k_export_samples, dim3((b.nSamples + 255) / 256), dim3(256), 0, s->stream, d, b, A[0], tg.dOut, s->dCounts.p);
-		HIPCHK(hipGetLastError());
+		RTX_LAUNCHED("k_accumulate / k_export_samples");
 		rc = end_event(s, ev);
 		if (rc) return rc;
 		HIPCHK(hipMemcpyAsync(s->hCounts, s->dCounts.p, COUNT_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
@@ -770,20 +838,38 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 		bool overflow = false;
 		for (int lv = 0; lv <= s->maxDepth; ++lv) overflow = overflow || s->hCounts[(size_t)(lv + 1) * CNT_STRIDE + 4] != 0;
 		// what the levels asked for, whether or not it fitted (the cursor runs on past the capacity)
-		for (int lv = 1; lv <= s->maxDepth; ++lv)
-			s->popRatio[lv] = std::max(s->popRatio[lv], (double)s->hCounts[(size_t)lv * CNT_STRIDE] / (double)b.nSamples);
+		double asked[MAX_DEPTH + 2];
+		asked[0] = 1.0;
+		for (int lv = 1; lv <= s->maxDepth; ++lv) asked[lv] = (double)s->hCounts[(size_t)lv * CNT_STRIDE] / (double)b.nSamples;
 		if (overflow) {
-			if (!useHistory) return fail(RTX_ERR_MEMORY, "child queue overflow (internal sizing error)");
-			// nothing of this batch was stored: once more, with queues that cannot overflow
+			// Nothing of this batch was stored.  The first level that asked for more than it had was fed by complete
+			// levels, so its count is the true one; the levels behind it saw only part of their parents.  They grow
+			// by the factor that level grew over its parent, level by level, and the batch is rendered again (in
+			// smaller batches if the arena no longer holds it at once).
+			int first = 1;
+			while (first < s->maxDepth && s->hCounts[(size_t)first * CNT_STRIDE] <= cap[first]) ++first;
+			if (s->worstCaseQueues || ++attempts > 40)
+				return fail(RTX_ERR_MEMORY, "child queue overflow at level " + std::to_string(first) + " (internal sizing error)");
+			const double growth = std::max(1.0, asked[first] / std::max(asked[first - 1], 1.0 / 64.0));
+			for (int lv = 1; lv <= s->maxDepth; ++lv) {
+				double want = asked[lv] * 1.3 + 1.0 / 64.0;
+				if (lv <= first) s->popRatio[lv] = std::max(s->popRatio[lv], asked[lv]);
+				else want = std::max(want, s->capRatio[lv - 1] * growth);
+				s->capRatio[lv] = std::min(worst_ratio(s, lv), std::max(s->capRatio[lv], want));
+			}
+			s->capKnown = std::max(s->capKnown, first);
 			s->stats.chunks--;
 			s->stats.queue_retries++;
-			rc = render_range(s, d, frame, tg, g0, g0 + nb, false);
-			if (rc) return rc;
-			continue;
+			continue;  // the same blocks once more, planned anew
 		}
+		for (int lv = 1; lv <= s->maxDepth; ++lv) {
+			s->popRatio[lv] = std::max(s->popRatio[lv], asked[lv]);
+			// 1.3 times the most seen so far plus a little, capped by the worst case
+			if (!s->worstCaseQueues) s->capRatio[lv] = std::min(worst_ratio(s, lv), s->popRatio[lv] * 1.3 + 1.0 / 64.0);
+		}
+		s->capKnown = s->maxDepth;
 		rc = check_fault(s->hCounts[FAULT_WORD]);
 		if (rc) return rc;
-		s->haveHistory = true;
 		uint64_t n = (uint64_t)b.nSamples;
 		for (int lv = 0; lv <= s->maxDepth; ++lv) {
 			const unsigned* hc = s->hCounts + (size_t)(lv + 1) * CNT_STRIDE;
@@ -796,6 +882,8 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 			s->stats.rays_wave_traced += s->hCounts[(size_t)lv * CNT_STRIDE + LONG_SLOT];
 			n = hc[0];
 		}
+		g0 += nb;
+		attempts = 0;
 	}
 	HIPCHK(hipStreamSynchronize(s->stream));
 	return harvest_events(s);
@@ -811,8 +899,12 @@ int render_batches(rtx_scene* s, uint32_t frame, uint32_t nFrames, int mode, int
 	const uint32_t perRound = (uint32_t)std::max<long long>(1, std::min<long long>(nFrames, 0x7FFF0000ll / SAMPLES_PER_BLOCK / blocksPerFrame));
 	for (uint32_t f = 0; f < nFrames; f += perRound) {
 		const uint32_t nf = std::min(perRound, nFrames - f);
-		int rc = render_range(s, d, frame + f, tg, 0, blocksPerFrame * nf, s->haveHistory && !s->worstCaseQueues);
-		if (rc) return rc;
+		int rc = render_range(s, d, frame + f, tg, 0, blocksPerFrame * nf);
+		if (rc) {
+			// an error may have left kernels of the batch enqueued: nothing may be freed or reused under them
+			(void)hipStreamSynchronize(s->stream);
+			return rc;
+		}
 	}
 	return RTX_OK;
 }
@@ -881,6 +973,7 @@ RTX_API int rtx_scene_create(rtx_scene** out, int device) {
 	if (const char* e = std::getenv("RTX_TRACE_TRI_BATCH")) s->traceTriBatch = std::max(1, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_TRACE_BLOCKS_PER_CU")) s->traceBlocksPerCU = std::max(1, std::atoi(e));
 	if (const char* e = std::getenv("RTX_TRACE_BINARY")) s->forceBinary = std::atoi(e) != 0;
+	if (const char* e = std::getenv("RTX_SYNC_LAUNCHES")) s->syncLaunches = std::atoi(e) != 0;
 	if (const char* e = std::getenv("RTX_WORST_CASE_QUEUES")) s->worstCaseQueues = std::atoi(e) != 0;
 	if (const char* e = std::getenv("RTX_WIDE_STACK")) s->wideStackCap = std::max(16, std::min(24, std::atoi(e)));
 	std::memset(&s->stats, 0, sizeof(s->stats));
@@ -921,8 +1014,7 @@ RTX_API int rtx_scene_set_params(rtx_scene* s, int width, int height, int max_de
 	for (int i = 0; i < 3; ++i) s->bg[i] = background_rgb[i];
 	s->seed = seed;
 	s->haveParams = true;
-	s->haveHistory = false;
-	std::fill(s->popRatio, s->popRatio + 17, 0.0);
+	s->haveCaps = false;
 	return RTX_OK;
 }
 
@@ -962,8 +1054,7 @@ RTX_API int rtx_scene_set_triangles(rtx_scene* s, const void* triangles, uint32_
 	s->maxTriTex = maxTex;
 	s->haveTris = true;
 	s->haveBvh = false;
-	s->haveHistory = false;
-	std::fill(s->popRatio, s->popRatio + 17, 0.0);
+	s->haveCaps = false;
 	return RTX_OK;
 }
 
@@ -1502,6 +1593,141 @@ RTX_API int rtx_sample_radiance(rtx_scene* s, uint32_t frame, float* host_out) {
 	dOut.release();
 	if (rc) return rc;
 	return finish_stats(s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Several GPUs in one process: the exchange step.
+
+namespace {
+
+struct Rccl {
+	void* lib = nullptr;
+	decltype(&ncclCommInitAll) commInitAll = nullptr;
+	decltype(&ncclCommDestroy) commDestroy = nullptr;
+	decltype(&ncclGroupStart) groupStart = nullptr;
+	decltype(&ncclGroupEnd) groupEnd = nullptr;
+	decltype(&ncclSend) send = nullptr;
+	decltype(&ncclRecv) recv = nullptr;
+	decltype(&ncclGetErrorString) errorString = nullptr;
+	std::vector<int> devices;        // the communicators below were made for these devices, in this order
+	std::vector<ncclComm_t> comms;
+};
+Rccl g_rccl;
+std::mutex g_rcclMutex;
+
+// Opens RCCL (the copy the process already holds, if any: a Python process that imported torch has torch's) and
+// looks the entry points up.
+int rccl_open(Rccl& r) {
+	if (r.lib) return RTX_OK;
+	const char* names[] = {"librccl.so", "librccl.so.1"};
+	for (const char* n : names)
+		if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+	for (const char* n : {"librccl.so.1", "librccl.so"})
+		if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+	if (!r.lib) return fail(RTX_ERR_DEVICE, std::string("cannot open RCCL (librccl.so): ") + dlerror());
+	r.commInitAll = (decltype(r.commInitAll))dlsym(r.lib, "ncclCommInitAll");
+	r.commDestroy = (decltype(r.commDestroy))dlsym(r.lib, "ncclCommDestroy");
+	r.groupStart = (decltype(r.groupStart))dlsym(r.lib, "ncclGroupStart");
+	r.groupEnd = (decltype(r.groupEnd))dlsym(r.lib, "ncclGroupEnd");
+	r.send = (decltype(r.send))dlsym(r.lib, "ncclSend");
+	r.recv = (decltype(r.recv))dlsym(r.lib, "ncclRecv");
+	r.errorString = (decltype(r.errorString))dlsym(r.lib, "ncclGetErrorString");
+	if (!r.commInitAll || !r.commDestroy || !r.groupStart || !r.groupEnd || !r.send || !r.recv || !r.errorString) {
+		r.lib = nullptr;
+		return fail(RTX_ERR_DEVICE, "the RCCL library lacks an entry point this library needs");
+	}
+	return RTX_OK;
+}
+
+#define RCCLCHK(expr)                                                                                             \
+	do {                                                                                                          \
+		ncclResult_t r_ = (expr);                                                                                 \
+		if (r_ != ncclSuccess) return fail(RTX_ERR_DEVICE, std::string(#expr) + ": " + g_rccl.errorString(r_));   \
+	} while (0)
+
+}  // namespace
+
+RTX_API int rtx_gather_tiles(rtx_scene* const* scenes, int n) {
+	if (!scenes || n < 1) return fail(RTX_ERR_ARG, "scenes is null or n < 1");
+	rtx_scene* s0 = scenes[0];
+	for (int r = 0; r < n; ++r) {
+		rtx_scene* s = scenes[r];
+		if (!s) return fail(RTX_ERR_ARG, "a scene is null");
+		if (!s->haveParams || s->width != s0->width || s->height != s0->height) return fail(RTX_ERR_ARG, "the scenes differ in image size");
+		if (s->tileFirst != r || s->tileStride != n || s->tileCount >= 0)
+			return fail(RTX_ERR_ARG, "scene r must hold the tile share (r, n): rtx_scene_set_tiles(scenes[r], r, n, -1)");
+		for (int q = 0; q < r; ++q)
+			if (scenes[q]->device == s->device && n > 1) return fail(RTX_ERR_ARG, "two scenes of one exchange on the same GPU");
+		const int rc = ensure_ready(s, false);
+		if (rc) return rc;
+	}
+	std::lock_guard<std::mutex> lk(g_rcclMutex);
+	int rc = rccl_open(g_rccl);
+	if (rc) return rc;
+	std::vector<int> devices(n);
+	for (int r = 0; r < n; ++r) devices[r] = scenes[r]->device;
+	if (g_rccl.devices != devices) {
+		for (ncclComm_t c : g_rccl.comms) (void)g_rccl.commDestroy(c);
+		g_rccl.comms.assign((size_t)n, nullptr);
+		g_rccl.devices.clear();
+		RCCLCHK(g_rccl.commInitAll(g_rccl.comms.data(), n, devices.data()));
+		g_rccl.devices = devices;
+	}
+	// a scene's own share stays where it is; with a single scene the share travels to itself, so that one GPU
+	// exercises every step of the exchange
+	const int firstSender = n == 1 ? 0 : 1;
+	const int tilesX = (s0->width + TILE - 1) / TILE;
+	const size_t slotsMax = (size_t)(num_tiles(s0) + n - 1) / (size_t)n;  // the largest share
+	const size_t perShare = slotsMax * TILE * TILE;                       // float4 per message
+	HIPCHK(hipSetDevice(s0->device));
+	if (s0->dTileRecv.n < perShare * (size_t)(n - firstSender)) HIPCHK(s0->dTileRecv.alloc(perShare * (size_t)(n - firstSender)));
+	for (int r = firstSender; r < n; ++r) {
+		rtx_scene* s = scenes[r];
+		HIPCHK(hipSetDevice(s->device));
+		if (s->dTilePack.n < perShare) HIPCHK(s->dTilePack.alloc(perShare));
+		const int slots = tile_slots(s);
+		if (slots > 0) {
+			hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)(((size_t)slots * TILE * TILE + 255) / 256)), dim3(256), 0, s->stream, s->dAccum,
+							   s->width, s->height, tilesX, s->tileFirst, s->tileStride, slots, s->dTilePack.p);
+			RTX_LAUNCHED("k_pack_tiles");
+			// RTX_GATHER_POISON=1 (tests, single scene only): what was packed is wiped from the image, so the image is
+			// whole again only if pack, send, receive and unpack all did their part
+			if (n == 1 && std::getenv("RTX_GATHER_POISON"))
+				HIPCHK(hipMemsetAsync(s->dAccum, 0xFF, (size_t)s->width * s->height * sizeof(float4), s->stream));
+		}
+	}
+	// one message per peer, all in one group: every peer's share crosses its own link to GPU 0 at the same time
+	RCCLCHK(g_rccl.groupStart());
+	for (int r = firstSender; r < n; ++r) {
+		rtx_scene* s = scenes[r];
+		const size_t count = (size_t)tile_slots(s) * TILE * TILE * 4;  // floats
+		if (!count) continue;
+		ncclResult_t a = g_rccl.send(s->dTilePack.p, count, ncclFloat, 0, g_rccl.comms[r], s->stream);
+		ncclResult_t b = a == ncclSuccess ? g_rccl.recv(s0->dTileRecv.p + perShare * (size_t)(r - firstSender), count, ncclFloat, r, g_rccl.comms[0], s0->stream) : a;
+		if (b != ncclSuccess) {
+			(void)g_rccl.groupEnd();
+			return fail(RTX_ERR_DEVICE, std::string("ncclSend/ncclRecv: ") + g_rccl.errorString(b));
+		}
+	}
+	RCCLCHK(g_rccl.groupEnd());
+	HIPCHK(hipSetDevice(s0->device));
+	for (int r = firstSender; r < n; ++r) {
+		rtx_scene* s = scenes[r];
+		const int slots = tile_slots(s);
+		if (slots <= 0) continue;
+		rtx_scene* sdst = s0;
+		{
+			rtx_scene* s = sdst;  // the launch check reports on the receiving scene's stream
+			hipLaunchKernelGGL(k_unpack_tiles, dim3((unsigned)(((size_t)slots * TILE * TILE + 255) / 256)), dim3(256), 0, s->stream, s->dAccum,
+							   s->width, s->height, tilesX, r, n, slots, s->dTileRecv.p + perShare * (size_t)(r - firstSender));
+			RTX_LAUNCHED("k_unpack_tiles");
+		}
+	}
+	for (int r = n - 1; r >= 0; --r) {
+		HIPCHK(hipSetDevice(scenes[r]->device));
+		HIPCHK(hipStreamSynchronize(scenes[r]->stream));
+	}
+	return RTX_OK;
 }
 
 RTX_API int rtx_scene_set_instrumented(rtx_scene* s, int enabled) {

@@ -603,6 +603,70 @@ def test_queue_history_overflow_is_rendered_again(libs):
     assert_bits_equal(fresh.accum(), rt2.accum(), "frames 3-4")
 
 
+@pytest.mark.parametrize("w,h,depth,nd,ns", [(8, 6, 8, 4, 4), (4, 2, 6, 8, 8)])
+def test_deep_branching_recursion_grows_its_queues_within_the_arena_limit(libs, w, h, depth, nd, ns):
+    """max_recursion_depth 8 with four diffuse and four specular rays per hit: the worst case is 8^8 rays per primary
+    sample (1.7 GB of queue each), the scene's real population some ten thousand.  The first frame starts from a
+    bounded guess, the device reports the level that outgrew it, the queues grow from the counts actually asked for
+    and the batch is rendered again -- never beyond the arena limit.  Accumulator and ray count == the CPU
+    restatement's recursion; the second frame needs no second try; a limit that one pixel block cannot meet is an
+    error that names the limit."""
+    sc = scenes.mixed_scene(seed=3, width=w, height=h, max_depth=depth, n_diff=nd, n_spec=ns, with_sky=True)
+    nodes = api.build_bvh(sc.tris)
+    O = binding.Oracle()
+    load_into(O, sc, build=False)
+    O.set_nodes(nodes)
+    want = np.zeros((h, w, 4), np.float32)
+    O.reset_counts()
+    O.render_rows(1, want, nthreads=16)
+    rays1 = O.ray_count()
+    assert rays1 > 2000 * w * h * 4
+    rt = api.RayTracer(0)
+    rt.load_scene(sc, nodes)
+    rt.set_arena_bytes(2 << 30)
+    rt.reset()
+    rt.render(1, 1)
+    st = rt.stats()
+    assert st["queue_retries"] >= 1
+    assert st["rays"] == rays1 and st["rays"] == sum(st["rays_per_level"])
+    assert_bits_equal(want[..., :3], rt.accum()[..., :3], "accumulator, frame 1")
+    O.render_rows(2, want, nthreads=16)
+    rt.render(2, 1)
+    assert rt.stats()["queue_retries"] == 0
+    assert_bits_equal(want[..., :3], rt.accum()[..., :3], "accumulator, frame 2")
+    small = api.RayTracer(0)
+    small.load_scene(sc, nodes)
+    small.set_arena_bytes(24 << 20)
+    small.reset()
+    with pytest.raises(api.RtxError) as e:
+        small.render(1, 1)
+    assert e.value.code == -4 and "work-arena limit of 24 MiB" in str(e.value) and "rtx_scene_set_arena_bytes" in str(e.value)
+
+
+def test_tile_exchange_over_rccl_on_one_gpu(libs, monkeypatch):
+    """rtx_gather_tiles, the exchange step of the several-GPUs-in-one-process drop-in, as far as one GPU can run it:
+    a single scene holds the share (0, 1), which is packed, sent to itself through RCCL (ncclCommInitAll over one
+    device, ncclSend + ncclRecv in one group) and unpacked.  With RTX_GATHER_POISON the image is overwritten between
+    pack and unpack, so it is whole again only if every step did its part.  Ragged image: the last tile column and
+    row are partial.  Shares that do not match (r, n) are refused."""
+    sc = scenes.mixed_scene(seed=4, width=200, height=150)
+    rt = gpu_scene(sc)
+    rt.reset()
+    rt.render(1, 2)
+    want = rt.accum()
+    assert want[..., :3].any()
+    monkeypatch.setenv("RTX_GATHER_POISON", "1")
+    api.gather_tiles([rt])
+    assert_bits_equal(want, rt.accum(), "image after pack -> wipe -> send/recv -> unpack")
+    api.gather_tiles([rt])                                   # communicator and buffers are reused
+    assert_bits_equal(want, rt.accum(), "second exchange")
+    monkeypatch.delenv("RTX_GATHER_POISON")
+    rt.set_tiles(1, 2, -1)
+    with pytest.raises(api.RtxError) as e:
+        api.gather_tiles([rt])
+    assert e.value.code == -1 and "tile share" in str(e.value)
+
+
 def test_device_tonemap_equals_host(libs):
     """rtx_tonemap_read (table search on the device) gives the bytes of the host tone map of
     src/RayTracer.cpp:248-257, on rendered accumulators and on synthetic ones with the awkward values."""
