@@ -29,7 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth of the 8 XCDs
 
 
 def cpu_baseline(sc, nodes, seconds_target=15.0):
@@ -76,15 +77,17 @@ def cpu_baseline(sc, nodes, seconds_target=15.0):
     }
 
 
-def measured_traffic():
-    """HBM bytes per traversal launch from the rocprofv3 PMC passes (FETCH_SIZE doubled as gfx950 needs, plus
-    WRITE_SIZE), as recorded by profiles/summarize.py into raytracer_amd/measured.json; None when absent."""
+def offline_profile():
+    """What profiles/summarize.py recorded from the rocprofv3 counter passes of this same command
+    (raytracer_amd/tools/collect_profile.sh) into raytracer_amd/measured.json: lane use and busy share of the
+    vector ALUs, fabric bytes per launch, the FETCH_SIZE calibration, and the commit it was taken at.  Counters
+    cannot be read from inside this process, so these figures are quoted, with their source, not re-measured."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "raytracer_amd", "measured.json")
     try:
         with open(path) as f:
-            return json.load(f).get("k_trace_wide_hbm_bytes_per_launch")
+            return json.load(f)
     except (OSError, ValueError):
-        return None
+        return {}
 
 
 def main():
@@ -92,8 +95,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=None, help="default: 1920 on one GPU, 3840 on several")
+    ap.add_argument("--height", type=int, default=None, help="default: 1080 on one GPU, 2160 on several")
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--balance", choices=["static", "dynamic"], default="static")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
@@ -101,6 +104,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-instrument", action="store_true")
     args = ap.parse_args()
+    args.size_given = args.width is not None or args.height is not None
+    args.width = args.width or 1920
+    args.height = args.height or 1080
 
     import torch
     import torch.distributed as dist
@@ -126,6 +132,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if world > 1 and not args.size_given:
+        args.width, args.height = 3840, 2160   # the multi-GPU configuration is quoted at 4K
     sc = scenes.atrium_scene(width=args.width, height=args.height, max_depth=args.depth)
     nodes = api.build_bvh(sc.tris)
     rt = api.RayTracer(local)
@@ -155,9 +163,9 @@ def main():
 
     frames_per_step = world if (args.scaling == "weak" and args.balance == "static") else 1
 
-    def step(frame):
+    def step(frame, nframes):
         if args.balance == "static":
-            rt.render(frame, frames_per_step)
+            rt.render(frame, nframes)
             take_stats()
             sharder.gather_static(accum)
         else:
@@ -180,47 +188,76 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    frame = 1
-    for _ in range(args.warmup):
-        step(frame)
-        frame += frames_per_step
-    for k in counters:
-        counters[k] = 0
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(frame)
-        frame += frames_per_step
-    sync()
-    dt = time.perf_counter() - t0
+    state = {"frame": 1}
 
-    tot = torch.tensor([dt, float(counters["rays"]), counters["trace_ms"], counters["shade_ms"]], dtype=torch.float64, device=dev)
-    if world > 1:
-        tmax = tot.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dt = float(tmax[0])
-    rays_total = float(tot[1])
-    trace_ms_sum = float(tot[2])
-    shade_ms_sum = float(tot[3])
+    def timed_loop(nframes, warmup, steps):
+        """`warmup` untimed steps, then `steps` timed ones between barriers; the time is the slowest rank's, the
+        counters are summed over the ranks."""
+        for _ in range(warmup):
+            step(state["frame"], nframes)
+            state["frame"] += nframes
+        for k in counters:
+            counters[k] = 0
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(state["frame"], nframes)
+            state["frame"] += nframes
+        sync()
+        dt = time.perf_counter() - t0
+        tot = torch.tensor([dt, float(counters["rays"]), counters["trace_ms"], counters["shade_ms"], float(counters["untraced"]),
+                            float(counters["launches"])], dtype=torch.float64, device=dev)
+        if world > 1:
+            tmax = tot.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            tot[0] = tmax[0]
+        return {"dt": float(tot[0]), "rays": float(tot[1]), "trace_ms": float(tot[2]), "shade_ms": float(tot[3]),
+                "untraced": float(tot[4]), "launches": float(tot[5])}
+
+    main_run = timed_loop(frames_per_step, args.warmup, args.steps)
+    dt, rays_total, trace_ms_sum, shade_ms_sum = main_run["dt"], main_run["rays"], main_run["trace_ms"], main_run["shade_ms"]
+    # With several GPUs the other way of scaling is timed as well: one frame per step, every rank its 1/N tile
+    # share of it (what the per-frame out_NNN.png contract of the reference costs).
+    other_run = None
+    if world > 1 and args.balance == "static":
+        other_frames = 1 if frames_per_step == world else world
+        other_run = timed_loop(other_frames, min(args.warmup, 2), args.steps)
+        other_run["frames_per_step"] = other_frames
 
     # node/triangle test counts of this rank's share, from one instrumented frame outside the timed region
-    # (frame `frame - 1` again: identical rays); they feed the algorithmic-bytes figure of the trace kernel.
+    # (the last frames again: identical rays); they feed the algorithmic-bytes figure of the trace kernel.
     n_node = n_tri = n_wide = n_leaf = None
+    ref_counts = None
     if not args.no_instrument and args.balance == "static":
         rt.set_instrumented(True)
-        rt.render(frame - frames_per_step, frames_per_step)
+        rt.render(state["frame"] - frames_per_step, frames_per_step)
         st = rt.stats()
-        rt.set_instrumented(False)
         n_node = st["node_tests"] / max(st["rays"], 1)
         n_tri = st["tri_tests"] / max(st["rays"], 1)
         n_wide = st["wide_visits"] / max(st["rays"], 1)
         n_leaf = st["leaf_fetches"] / max(st["rays"], 1)
+        if rank == 0 and world == 1:
+            # What the reference's own traversal does per ray, for context: BVH::hit visits every node whose box the
+            # ray meets and hands every such leaf to Triangle::hit, without ordering or culling by the best hit
+            # (/root/reference/src/BVH.cpp:162-192).  Counted by the exhaustive mode of the binary-tree kernel
+            # (that same candidate set) on the primary rays, beside the production traversal on the same rays.
+            rt.primary_hits(1, want_tab=False)
+            ex = rt.stats()
+            rt.primary_hits(0, want_tab=False)
+            cu = rt.stats()
+            ref_counts = {"rays": "primary (%d)" % ex["rays"],
+                          "box_tests_per_ray": round(ex["node_tests"] / max(ex["rays"], 1), 2),
+                          "triangle_tests_per_ray": round(ex["tri_tests"] / max(ex["rays"], 1), 2),
+                          "this_path_box_tests_per_ray": round(cu["node_tests"] / max(cu["rays"], 1), 2),
+                          "this_path_triangle_tests_per_ray": round(cu["tri_tests"] / max(cu["rays"], 1), 2)}
+        rt.set_instrumented(False)
 
     if rank == 0:
         samples = sc.width * sc.height * 4 * args.steps * frames_per_step
         out = {
-            "metric": "Mrays/s (incl. secondary) at 1080p", "value": round(rays_total / dt / 1e6, 2), "unit": "Mrays/s",
+            "metric": "Mrays/s (incl. secondary) at %s" % ("1080p" if (sc.width, sc.height) == (1920, 1080) else "%dx%d" % (sc.width, sc.height)),
+            "value": round(rays_total / dt / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak" if frames_per_step == world else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "atrium (Sponza-class, %d triangles, %d textures + cube-map sky) %dx%d, 4 spp per step, "
@@ -230,28 +267,53 @@ def main():
                        "sharding": "tile-interleave x%d, %s" % (world, "gather to rank 0 per step" if args.balance == "static" else "dynamic batches + reduce per step")},
             "samples_per_s": round(samples / dt, 1),
             "rays_per_step": round(rays_total / args.steps),
-            # rays of the last level that are worth zero hit or miss (counted above: the reference traces them);
-            # this rank's share
-            "rays_untraced_per_step": round(counters["untraced"] / args.steps),
+            # rays of the last level that are worth zero hit or miss are counted in `value` (they are color() queries the
+            # reference traces) but are answered without traversal; the rate over the traversed rays alone stands beside it
+            "rays_untraced_per_step": round(main_run["untraced"] / args.steps),
+            "traversed_Mrays_per_s": round((rays_total - main_run["untraced"]) / dt / 1e6, 2),
             "gpu_kernel_ms_per_step": {"trace": round(trace_ms_sum / args.steps / world, 3), "shade_gather_accumulate": round(shade_ms_sum / args.steps / world, 3)},
         }
+        if other_run is not None:
+            o = other_run
+            out["other_scaling"] = {"scaling": "strong" if o["frames_per_step"] == 1 else "weak", "frames_per_step": o["frames_per_step"],
+                                    "value": round(o["rays"] / o["dt"] / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(o["dt"] / args.steps * 1e3, 3),
+                                    "ms_per_frame": round(o["dt"] / args.steps / o["frames_per_step"] * 1e3, 3)}
         if n_node is not None:
-            # algorithmic bytes the traversal kernel must move per ray: one 64-B record per node of the 4-wide
-            # tree it visits, one 64-B record per triangle whose quantised box it enters, 32 B ray in, 16 B hit out
-            # (a ray that is not traversed has only its direction read: 16 B less)
-            bytes_per_ray = 64.0 * n_wide + 64.0 * n_leaf + 48.0 - 16.0 * counters["untraced"] * world / max(rays_total, 1.0)
-            achieved = bytes_per_ray * rays_total / (trace_ms_sum * 1e-3) / 1e9 if trace_ms_sum > 0 else 0.0  # per GPU: both sums run over the ranks
-            out["roofline"] = {"bound": "hbm", "kernel": "k_trace_wide", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),
-                               "node_visits_per_ray": round(n_wide, 2), "leaf_fetches_per_ray": round(n_leaf, 3),
-                               "box_tests_per_ray": round(n_node, 2), "triangle_tests_per_ray": round(n_tri, 3),
-                               "bytes_per_ray": round(bytes_per_ray, 1),
-                               "avg_launch_ms": round(trace_ms_sum / max(counters["launches"] * world, 1), 4),
-                               "traffic_GBps": (round(measured_traffic() / (trace_ms_sum / max(counters["launches"] * world, 1) * 1e-3) / 1e9, 1)
-                                                if measured_traffic() and trace_ms_sum > 0 else None),
-                               "note": "the records are re-read from L2/Infinity Cache (tree + triangles = 25 MB), so algorithmic "
-                                       "bytes/s can approach the HBM figure without HBM traffic; the kernel's measured limiter is "
-                                       "vector-ALU issue (SQ_ACTIVE_INST_VALU ~ 98 % of SIMD cycles), see profiles/"}
+            # Algorithmic bytes the traversal must move per ray: one 64-B record per node of the 4-wide tree it visits,
+            # one 64-B record per triangle whose quantised box it enters, 32 B ray in, 16 B hit out (a ray that is not
+            # traversed has only its direction read: 16 B less).  Launch duration: HIP events around every level's
+            # traversal on the scene's stream (rtx_stats.trace_ms / trace_launches), live, in the timed region.
+            launches = max(main_run["launches"], 1.0)
+            avg_launch_ms = trace_ms_sum / launches
+            bytes_per_ray = 64.0 * n_wide + 64.0 * n_leaf + 48.0 - 16.0 * main_run["untraced"] / max(rays_total, 1.0)
+            algo_gbs = bytes_per_ray * rays_total / (trace_ms_sum * 1e-3) / 1e9 if trace_ms_sum > 0 else 0.0  # per GPU: both sums run over the ranks
+            prof = offline_profile()
+            pk = prof.get("k_trace_wide", {})
+            rays_per_launch = rays_total / launches
+            traffic = None
+            if "fetch_size_bytes_per_launch" in pk:
+                # FETCH_SIZE is 64 B x fabric read requests; a request for a random 64-byte record carries 64 B (measured
+                # factor 0.98), a streamed line 128 B (factor 2.0): the 32 B per ray of the queue read are added once more
+                traffic = round(pk["fetch_size_bytes_per_launch"] + pk["write_size_bytes_per_launch"] + 16.0 * rays_per_launch)
+            roof = {"kernel": "k_trace_wide",
+                    # neither of the two standard ceilings binds this kernel: its 25 MB of nodes and triangles are re-read from
+                    # L2 / Infinity Cache, and it has no matrix work; the counters show the vector ALUs saturated, so the
+                    # ceiling is vector-ALU lane-cycles and the figure is the share of them that does useful work
+                    "bound": "valu", "achieved": round(100.0 * pk["valu_frac"], 2) if "valu_frac" in pk else None, "peak": 100.0,
+                    "unit": "% of vector-ALU lane-cycles", "frac": pk.get("valu_frac"),
+                    "valu_busy": pk.get("valu_busy"), "valu_busy_raw": pk.get("valu_busy_raw"), "lane_util": pk.get("lane_util"),
+                    "valu_lane_slots_per_ray": round(pk["valu_insts_per_launch"] * 64.0 / rays_per_launch, 1) if "valu_insts_per_launch" in pk else None,
+                    "counters_from": "%s @ %s (rocprofv3 passes of this command, raytracer_amd/tools/collect_profile.sh)" % (prof.get("source"), prof.get("commit")) if prof else None,
+                    "traffic": traffic,
+                    "traffic_GBps": round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1) if traffic else None,
+                    "algorithmic": {"bytes_per_ray": round(bytes_per_ray, 1), "GBps": round(algo_gbs, 1),
+                                    "frac_of_hbm_8000": round(algo_gbs / HBM_PEAK_GBS, 4), "frac_of_l2_34500": round(algo_gbs / L2_PEAK_GBS, 4)},
+                    "avg_launch_ms": round(avg_launch_ms, 4),
+                    "node_visits_per_ray": round(n_wide, 2), "leaf_fetches_per_ray": round(n_leaf, 3),
+                    "box_tests_per_ray": round(n_node, 2), "triangle_tests_per_ray": round(n_tri, 3)}
+            if ref_counts:
+                roof["reference_traversal_for_context"] = ref_counts
+            out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, nodes)
         print(json.dumps(out))

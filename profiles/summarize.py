@@ -1,13 +1,27 @@
-"""Condenses rocprofv3 CSV output (kernel-trace stats and --pmc passes) into the text summaries kept in
-this directory, and records the HBM bytes per launch of the traversal kernel (FETCH_SIZE doubled, as gfx950
-needs for wide loads, plus WRITE_SIZE; both in KiB) in raytracer_amd/measured.json, where bench.py picks it up.
-Usage: python profiles/summarize.py <dir with kt/ fetch/ write/ sq/ cache/> <out.txt>"""
+"""Condenses the rocprofv3 CSV output of raytracer_amd/tools/collect_profile.sh into the text summaries kept in this
+directory and into raytracer_amd/measured.json, the offline figures bench.py quotes beside its live ones.
+
+    python profiles/summarize.py <dir with kt/ sq/ sq2/ grbm/ fetch/ write/ cache/ calib_*/> <out.txt>
+
+What is derived for the traversal kernel k_trace_wide (all template variants together):
+  lane_util   = SQ_THREAD_CYCLES_VALU / (64 * SQ_INSTS_VALU): active lanes per vector-ALU instruction / 64
+  valu_busy   = 4 * SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 * SIMDs): SQ_ACTIVE_INST_VALU counts quad-cycles of
+                waves with a vector instruction in flight, GRBM_GUI_ACTIVE is summed over the 8 XCDs; the two come
+                from different runs, and an instruction that issues in 2 cycles still counts 4, so the quotient can
+                exceed 1: read it as "saturated" then
+  fabric bytes: FETCH_SIZE and WRITE_SIZE are KiB.  FETCH_SIZE is 64 B x read requests of the L2 to the fabric
+                whatever a request carries; the calibration runs (tools/fetch_calib) give the factor per access
+                pattern: ~1.0 for random 64-byte records, 2.0 for random 128-byte records and for streams.
+"""
 import collections
 import csv
 import glob
 import json
 import os
+import subprocess
 import sys
+
+SIMDS = 256 * 4
 
 
 def short(name):
@@ -15,47 +29,155 @@ def short(name):
     return name.split("(")[0]
 
 
+def read_pass(src, sub):
+    files = glob.glob(src + "/" + sub + "/*/*counter_collection.csv")
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    calls = collections.Counter()
+    rows = []
+    if files:
+        for r in csv.DictReader(open(files[0])):
+            k = short(r["Kernel_Name"])
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            calls[(k, r["Counter_Name"])] += 1
+            rows.append((k, r["Counter_Name"], float(r["Counter_Value"])))
+    return agg, calls, rows
+
+
+def family(agg, calls, prefix, counter):
+    """Sum of a counter over every kernel whose name starts with prefix, and the number of dispatches.  The
+    instrumented variants (last template argument true; bench.py runs them once, outside the timed region, for its
+    test counts) are left out."""
+    tot, n = 0.0, 0
+    for k in agg:
+        if k.startswith(prefix) and not k.endswith("true>") and counter in agg[k]:
+            tot += agg[k][counter]
+            n += calls[(k, counter)]
+    return tot, n
+
+
+def git_state():
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    try:
+        h = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+        dirty = subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "raytracer_amd/csrc", "bench.py"], text=True).strip()
+        return h + ("+uncommitted" if dirty else "")
+    except Exception:
+        return "unknown"
+
+
 def main(src, dst):
     out = []
+    measured = {"source": "profiles/" + os.path.basename(dst), "commit": git_state()}
+    kt_ms = {}
     for f in glob.glob(src + "/kt/*/*kernel_stats.csv"):
         out.append("== rocprofv3 --kernel-trace --stats  (per kernel: calls, total ms, average us, share)")
         for r in csv.DictReader(open(f)):
             out.append("%-44s calls %5s  total %10.3f ms  avg %10.1f us  %6.2f %%" % (
                 short(r["Name"])[:44], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
-    for sub, title in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("sq", "SQ counters"), ("cache", "cache counters")):
-        files = glob.glob(src + "/" + sub + "/*/*counter_collection.csv")
-        if not files:
+            kt_ms[short(r["Name"])] = (float(r["TotalDurationNs"]) / 1e6, int(r["Calls"]))
+    passes = {}
+    for sub, title in (("sq", "SQ counters"), ("sq2", "SQ instruction mix"), ("grbm", "GRBM (clock)"), ("fetch", "FETCH_SIZE"),
+                       ("write", "WRITE_SIZE"), ("cache", "cache counters")):
+        agg, calls, _ = read_pass(src, sub)
+        passes[sub] = (agg, calls)
+        if not agg:
             continue
-        agg = collections.defaultdict(lambda: collections.defaultdict(float))
-        calls = collections.Counter()
-        for r in csv.DictReader(open(files[0])):
-            k = short(r["Kernel_Name"])
-            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            calls[(k, r["Counter_Name"])] += 1
         out.append("")
         out.append("== rocprofv3 --pmc pass: %s  (sums over all dispatches of the kernel; n = dispatches)" % title)
         for k in sorted(agg):
             for c in sorted(agg[k]):
                 out.append("%-44s %-30s %16.6g  n=%d" % (k[:44], c, agg[k][c], calls[(k, c)]))
-    traffic = {}
-    for sub, scale in (("fetch", 2.0), ("write", 1.0)):
-        files = glob.glob(src + "/" + sub + "/*/*counter_collection.csv")
-        if not files:
+
+    # ---- calibration of FETCH_SIZE
+    calib = {}
+    for M in (25, 1024):
+        _, _, rows = read_pass(src, "calib_fetch_%d" % M)
+        _, _, req = read_pass(src, "calib_req_%d" % M)
+        if not rows:
             continue
-        for r in csv.DictReader(open(files[0])):
-            if short(r["Kernel_Name"]).startswith("k_trace_wide") and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
-                t = traffic.setdefault(sub, [0.0, 0])
-                t[0] += float(r["Counter_Value"]) * 1024.0 * scale
-                t[1] += 1
-    if "fetch" in traffic and "write" in traffic and traffic["fetch"][1] == traffic["write"][1]:
-        per_launch = (traffic["fetch"][0] + traffic["write"][0]) / traffic["fetch"][1]
+        threads, reads = 1 << 21, 8
+        asked = {"k_random_records<4>": threads * reads * 64.0, "k_random_records<8>": threads * reads * 128.0, "k_stream": M * 1048576.0}
+        last = {}
+        for k, c, v in rows:      # the second round of every kernel is the warm one
+            if c == "FETCH_SIZE" and k in asked:
+                last[k] = v
+        lastreq = {}
+        for k, c, v in req:
+            if c == "TCC_EA0_RDREQ_sum" and k in asked:
+                lastreq[k] = v
+        for k in sorted(last):
+            calib[(M, k)] = (asked[k], last[k] * 1024.0, lastreq.get(k))
+    if calib:
         out.append("")
-        out.append("== k_trace_wide HBM traffic per launch: (2 x FETCH_SIZE + WRITE_SIZE) / %d launches = %.4g bytes" % (traffic["fetch"][1], per_launch))
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "raytracer_amd", "measured.json")
-        json.dump({"k_trace_wide_hbm_bytes_per_launch": round(per_launch), "launches": traffic["fetch"][1],
-                   "source": os.path.basename(dst)}, open(path, "w"), indent=1)
+        out.append("== FETCH_SIZE calibration (tools/fetch_calib; second round of each kernel): bytes the kernel asked for, FETCH_SIZE x 1024,")
+        out.append("   factor = asked / reported, fabric read requests (TCC_EA0_RDREQ_sum) and bytes asked per request")
+        for (M, k), (asked, rep, rq) in sorted(calib.items()):
+            out.append("table %5d MiB  %-22s asked %12.4g B  FETCH_SIZE %12.4g B  factor %.3f  requests %s  asked/request %s" % (
+                M, k, asked, rep, asked / rep, "%.4g" % rq if rq else "-", "%.1f B" % (asked / rq) if rq else "-"))
+        for M in (25, 1024):
+            p = os.path.join(src, "calib_%d.log" % M)
+            if os.path.exists(p):
+                out.append("   un-profiled run, %d MiB table:" % M)
+                out.extend("     " + line.rstrip() for line in open(p) if line.startswith("k_"))
+        f64 = calib.get((1024, "k_random_records<4>"))
+        f128 = calib.get((1024, "k_random_records<8>"))
+        fst = calib.get((1024, "k_stream"))
+        measured["fetch_size_factor"] = {"random_64B_records": round(f64[0] / f64[1], 3) if f64 else None,
+                                         "random_128B_records": round(f128[0] / f128[1], 3) if f128 else None,
+                                         "stream": round(fst[0] / fst[1], 3) if fst else None}
+
+    # ---- the traversal kernel
+    sq, sqc = passes.get("sq", ({}, {}))
+    sq2, sq2c = passes.get("sq2", ({}, {}))
+    gr, grc = passes.get("grbm", ({}, {}))
+    fe, fec = passes.get("fetch", ({}, {}))
+    wr, wrc = passes.get("write", ({}, {}))
+    K = "k_trace_wide"
+    insts, n = family(sq, sqc, K, "SQ_INSTS_VALU")
+    if n:
+        thr, _ = family(sq, sqc, K, "SQ_THREAD_CYCLES_VALU")
+        act, _ = family(sq, sqc, K, "SQ_ACTIVE_INST_VALU")
+        wavecyc, _ = family(sq, sqc, K, "SQ_WAVE_CYCLES")
+        gui, ng = family(gr, grc, K, "GRBM_GUI_ACTIVE")
+        salu, _ = family(sq2, sq2c, K, "SQ_INSTS_SALU")
+        vmem, _ = family(sq2, sq2c, K, "SQ_INSTS_VMEM_RD")
+        lds, _ = family(sq2, sq2c, K, "SQ_INSTS_LDS")
+        lane_util = thr / (64.0 * insts)
+        rec = {"launches": n, "valu_insts_per_launch": round(insts / n), "lane_util": round(lane_util, 4),
+               "active_lanes_per_valu_inst": round(64.0 * lane_util, 2)}
+        out.append("")
+        out.append("== %s (the variants of the timed region, %d dispatches): vector-ALU model" % (K, n))
+        out.append("   SQ_INSTS_VALU %.4g  SQ_THREAD_CYCLES_VALU %.4g  ->  %.1f of 64 lanes active per vector instruction (lane_util %.3f)" % (
+            insts, thr, 64.0 * lane_util, lane_util))
+        if ng:
+            cycles = gui / 8.0
+            busy = 4.0 * act / (cycles * SIMDS)
+            rec["valu_busy_raw"] = round(busy, 3)
+            rec["valu_busy"] = round(min(1.0, busy), 3)
+            rec["waves_per_simd"] = round(4.0 * wavecyc / (cycles * SIMDS), 2)
+            out.append("   4 x SQ_ACTIVE_INST_VALU %.4g  /  (GRBM_GUI_ACTIVE / 8 = %.4g cycles x %d SIMDs)  ->  valu_busy %.3f%s; %.2f waves per SIMD resident" % (
+                4.0 * act, cycles, SIMDS, busy, " (>= 1: saturated)" if busy >= 1 else "", rec["waves_per_simd"]))
+            out.append("   useful share of the vector-ALU lane-cycles = min(1, valu_busy) x lane_util = %.3f" % (min(1.0, busy) * lane_util))
+            rec["valu_frac"] = round(min(1.0, busy) * lane_util, 4)
+        if salu:
+            out.append("   per vector instruction: %.3f scalar, %.4f vector-memory reads, %.4f LDS" % (salu / insts, vmem / insts, lds / insts))
+        f, nf = family(fe, fec, K, "FETCH_SIZE")
+        w, nw = family(wr, wrc, K, "WRITE_SIZE")
+        if nf and nw:
+            rec["fetch_size_bytes_per_launch"] = round(f * 1024.0 / nf)
+            rec["write_size_bytes_per_launch"] = round(w * 1024.0 / nw)
+            out.append("   fabric traffic per launch: FETCH_SIZE %.4g B (= 64 B x read requests; x1 if they are 64-byte records, x2 if whole lines), WRITE_SIZE %.4g B" % (
+                f * 1024.0 / nf, w * 1024.0 / nw))
+        if K + "<24, false, false>" in kt_ms or any(k.startswith(K) for k in kt_ms):
+            tot = sum(v[0] for k, v in kt_ms.items() if k.startswith(K) and not k.endswith("true>"))
+            cnt = sum(v[1] for k, v in kt_ms.items() if k.startswith(K) and not k.endswith("true>"))
+            rec["kernel_trace_avg_launch_ms"] = round(tot / cnt, 4)
+            out.append("   kernel trace: %d launches, %.3f ms in all, %.4f ms per launch" % (cnt, tot, tot / cnt))
+        measured[K] = rec
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "raytracer_amd", "measured.json")
+    json.dump(measured, open(path, "w"), indent=1)
     open(dst, "w").write("\n".join(out) + "\n")
-    print("\n".join(out))
+    print("\n".join(out[-40:]))
 
 
 if __name__ == "__main__":

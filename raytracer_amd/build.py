@@ -73,10 +73,26 @@ def build_cli(force=False, verbose=False):
     return CLI_BIN
 
 
+def build_tools(force=False, verbose=False):
+    """tools/fetch_calib: the microbenchmark that calibrates rocprofv3's FETCH_SIZE (see tools/collect_profile.sh)."""
+    src = os.path.join(PKG, "tools", "fetch_calib.hip")
+    out = os.path.join(PKG, "tools", "fetch_calib")
+    if not os.path.exists(src):
+        return None
+    if not force and _newer(out, [src]):
+        return out
+    cmd = [_hipcc(), "-O2", "-std=c++17", "--offload-arch=gfx950", src, "-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_all(force=False, verbose=False):
     build_hip(force, verbose)
     build_host(force, verbose)
     build_cli(force, verbose)
+    build_tools(force, verbose)
 
 
 if __name__ == "__main__":

@@ -399,65 +399,68 @@ private:
 	void render(const std::string& outDir, int nDevices);
 };
 
-// src/RayTracer.cpp:20-106
+// The model keyword of the config file (src/RayTracer.cpp:20-106): one mesh becomes triangle records.
+// Done in bulk over the mesh arrays rather than corner by corner: every vertex is placed once (position * scale +
+// origin, w lane 0 * scale + origin.w, as the reference's Vector4f expression gives), the fields all triangles of
+// the model share are written into one template record, and a face then is the template plus three gathers.
 void HostRayTracer::loadModel(const std::string& modelPath, const Vec4& origin, float scale, bool isMetal,
 							  bool isLightEmitting, bool isTransparent, float specularRoughness, float refIndex,
 							  const std::optional<std::string>& texturePath, const std::optional<Vec4>& color) {
 	Mesh mesh;
 	if (!load_mesh(resolve(modelPath), mesh)) throw std::runtime_error("Can't load model in " + modelPath);
-	const Vec4 finalColor = color.has_value() ? color.value() : Vec4{mesh.diffuse[0], mesh.diffuse[1], mesh.diffuse[2], 0.0f};
 
-	bool useTexture = texturePath.has_value();
-	if (useTexture) {
-		useTexture = !mesh.uv.empty();
-		if (useTexture) {
-			Image tex;
-			if (!load_texture_file(resolve(texturePath.value()), tex)) {
-				useTexture = false;
-				std::cout << "Can't load texture in " << texturePath.value() << std::endl;
-			}
-			else
-				texturesArray.push_back(std::move(tex));
+	// texture: only for a mesh that has coordinates, and only if the file decodes; both failures are reported on
+	// stdout in the reference's words and the model is kept, untextured
+	int32_t textureId = -1;
+	if (texturePath) {
+		Image img;
+		if (mesh.uv.empty()) {
+			std::cout << "No texture for model in " << modelPath << std::endl;
 		}
-		if (!useTexture) std::cout << "No texture for model in " << modelPath << std::endl;
+		else if (!load_texture_file(resolve(*texturePath), img)) {
+			std::cout << "Can't load texture in " << *texturePath << std::endl;
+			std::cout << "No texture for model in " << modelPath << std::endl;
+		}
+		else {
+			texturesArray.push_back(std::move(img));
+			textureId = (int32_t)texturesArray.size() - 1;
+		}
 	}
 
-	const size_t faceNum = mesh.idx.size() / 3;
-	trianglesArray.reserve(faceNum + trianglesArray.size());
-	for (size_t j = 0; j < faceNum; ++j) {
-		TriangleRec tri;
-		std::memset(&tri, 0, sizeof(tri));
+	TriangleRec proto;
+	std::memset(&proto, 0, sizeof(proto));
+	proto.color = color ? *color : Vec4{mesh.diffuse[0], mesh.diffuse[1], mesh.diffuse[2], 0.0f};
+	proto.metal = isMetal;
+	proto.emit = isLightEmitting;
+	proto.transp = isTransparent;
+	proto.rough = specularRoughness;
+	proto.ior = refIndex;
+	proto.tex = textureId;
+
+	const size_t nVerts = mesh.pos.size() / 3;
+	std::vector<Vec4> placed(nVerts);
+	for (size_t v = 0; v < nVerts; ++v)
+		placed[v] = Vec4{mesh.pos[3 * v] * scale + origin.x, mesh.pos[3 * v + 1] * scale + origin.y, mesh.pos[3 * v + 2] * scale + origin.z,
+						 0.0f * scale + origin.w};
+
+	const bool smooth = !mesh.nrm.empty();
+	const size_t base = trianglesArray.size(), nFaces = mesh.idx.size() / 3;
+	trianglesArray.resize(base + nFaces, proto);
+	for (size_t f = 0; f < nFaces; ++f) {
+		TriangleRec& t = trianglesArray[base + f];
+		const uint32_t* corner = &mesh.idx[3 * f];
+		for (int k = 0; k < 3; ++k) t.v[k] = placed[corner[k]];
+		t.pn = normalized(cross3(sub(t.v[1], t.v[0]), sub(t.v[2], t.v[0])));
 		for (int k = 0; k < 3; ++k) {
-			const uint32_t index = mesh.idx[j * 3 + k];
-			const float* p = &mesh.pos[(size_t)index * 3];
-			// Vector4f(x, y, z, 0) * scale + origin
-			tri.v[k] = Vec4{p[0] * scale + origin.x, p[1] * scale + origin.y, p[2] * scale + origin.z, 0.0f * scale + origin.w};
-			if (useTexture) {
-				tri.uv[k][0] = mesh.uv[(size_t)index * 2];
-				tri.uv[k][1] = mesh.uv[(size_t)index * 2 + 1];
+			// a file without normals gets the face normal at every corner (what the importer's GenNormals step gives
+			// a flat face; for a positive scale that is the plane normal)
+			if (smooth) t.n[k] = Vec4{mesh.nrm[3 * (size_t)corner[k]], mesh.nrm[3 * (size_t)corner[k] + 1], mesh.nrm[3 * (size_t)corner[k] + 2], 0.0f};
+			else t.n[k] = t.pn;
+			if (textureId >= 0) {
+				t.uv[k][0] = mesh.uv[2 * (size_t)corner[k]];
+				t.uv[k][1] = mesh.uv[2 * (size_t)corner[k] + 1];
 			}
 		}
-		tri.pn = normalized(cross3(sub(tri.v[1], tri.v[0]), sub(tri.v[2], tri.v[0])));
-		for (int k = 0; k < 3; ++k) {
-			if (!mesh.nrm.empty()) {
-				const float* n = &mesh.nrm[(size_t)mesh.idx[j * 3 + k] * 3];
-				tri.n[k] = Vec4{n[0], n[1], n[2], 0.0f};
-			}
-			else {
-				// files without normals get per-face normals (the importer's GenNormals step);
-				// here: the unit face normal of the untransformed triangle, which for a positive
-				// scale is the plane normal
-				tri.n[k] = tri.pn;
-			}
-		}
-		tri.metal = isMetal;
-		tri.emit = isLightEmitting;
-		tri.transp = isTransparent;
-		tri.rough = specularRoughness;
-		tri.ior = refIndex;
-		tri.color = finalColor;
-		tri.tex = useTexture ? (int32_t)texturesArray.size() - 1 : -1;
-		trianglesArray.push_back(tri);
 	}
 }
 

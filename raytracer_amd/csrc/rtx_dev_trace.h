@@ -376,6 +376,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
 	unsigned boxTests = 0, triTests = 0, nodeVisits = 0, leafFetches = 0;
 	unsigned walkIters = 0, leafIters = 0, walkLanes = 0, leafLanes = 0;  // wave-level, kept by lane 0
+	unsigned walkIdle = 0, walkParked = 0, walkLeafWait = 0, leafIdle = 0, leafWalkers = 0, refills = 0, refillLanes = 0;  // likewise
 	unsigned overflows = 0;
 	unsigned myVisits = 0, maxVisits = 0, over100 = 0, over300 = 0;
 	int cnext = 0, cend = 0;
@@ -420,6 +421,10 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 			}
 			const int take = min(nidle, cend - cnext);
 			if (take > 0) {
+				if (STATS) {
+					refills++;
+					refillLanes += take;
+				}
 				const int slot = __popcll(idle & below);
 				if (!busy && slot < take) {
 					j = cnext + slot;
@@ -488,10 +493,15 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 			if (leafPhase) {
 				leafIters++;
 				leafLanes += __popcll(mLeaf);
+				leafIdle += __popcll(__builtin_amdgcn_ballot_w64(!busy));
+				leafWalkers += __popcll(mWalk & ~mLeaf);
 			}
 			else {
 				walkIters++;
 				walkLanes += __popcll(mWalk);
+				walkIdle += __popcll(__builtin_amdgcn_ballot_w64(!busy));
+				walkParked += __popcll(__builtin_amdgcn_ballot_w64(busy && pend1 >= 0));
+				walkLeafWait += __popcll(__builtin_amdgcn_ballot_w64(busy && pend1 < 0 && cur < 0 && sp == 0));
 			}
 		}
 		if (leafPhase) {
@@ -678,6 +688,13 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 			atomicAdd(&stats[3], (unsigned long long)walkLanes);
 			atomicAdd(&stats[6], (unsigned long long)leafIters);
 			atomicAdd(&stats[7], (unsigned long long)leafLanes);
+			atomicAdd(&stats[12], (unsigned long long)walkIdle);
+			atomicAdd(&stats[13], (unsigned long long)walkParked);
+			atomicAdd(&stats[14], (unsigned long long)walkLeafWait);
+			atomicAdd(&stats[15], (unsigned long long)leafIdle);
+			atomicAdd(&stats[16], (unsigned long long)leafWalkers);
+			atomicAdd(&stats[17], (unsigned long long)refills);
+			atomicAdd(&stats[18], (unsigned long long)refillLanes);
 		}
 		for (int off = 32; off > 0; off >>= 1) overflows += __shfl_down(overflows, off, 64);
 		if (lane == 0) {

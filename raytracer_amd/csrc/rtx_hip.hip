@@ -254,6 +254,7 @@ struct rtx_scene {
 namespace {
 
 constexpr int MAX_DEPTH = 15;
+constexpr int STATS_WORDS = 24;  // test counters of the instrumented traversal kernels (rtx_scene_set_instrumented)
 constexpr int FAULT_WORD = (MAX_DEPTH + 2) * CNT_STRIDE;  // behind the level blocks: the kernels' consistency checks (DevScene::fault)
 constexpr int COUNT_WORDS = FAULT_WORD + CNT_STRIDE;
 
@@ -378,9 +379,9 @@ int ensure_ready(rtx_scene* s, bool needCamera) {
 	}
 	if (!s->dCounts.p) {
 		HIPCHK(s->dCounts.alloc(COUNT_WORDS));
-		HIPCHK(s->dStats.alloc(12));
+		HIPCHK(s->dStats.alloc(STATS_WORDS));
 		HIPCHK(hipHostMalloc((void**)&s->hCounts, COUNT_WORDS * sizeof(unsigned), hipHostMallocDefault));
-		HIPCHK(hipHostMalloc((void**)&s->hStats, 12 * sizeof(unsigned long long), hipHostMallocDefault));
+		HIPCHK(hipHostMalloc((void**)&s->hStats, STATS_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
 	}
 	return RTX_OK;
 }
@@ -911,13 +912,17 @@ int render_batches(rtx_scene* s, uint32_t frame, uint32_t nFrames, int mode, int
 
 int finish_stats(rtx_scene* s) {
 	if (s->instrumented) {
-		HIPCHK(hipMemcpy(s->hStats, s->dStats.p, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(s->hStats, s->dStats.p, STATS_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 		s->stats.node_tests = s->hStats[0];
 		s->stats.tri_tests = s->hStats[1];
 		if (std::getenv("RTX_TRACE_DEBUG")) {
 			std::fprintf(stderr, "[rtx] wide: walk iterations %llu with %.1f lanes, leaf phases %llu with %.1f lanes, %llu stack overflows\n", s->hStats[2],
 						 (double)s->hStats[3] / (double)std::max(1ull, s->hStats[2]), s->hStats[6],
 						 (double)s->hStats[7] / (double)std::max(1ull, s->hStats[6]), s->hStats[8]);
+			const double wi = (double)std::max(1ull, s->hStats[2]), li = (double)std::max(1ull, s->hStats[6]);
+			std::fprintf(stderr, "[rtx] wide: per walk iteration %.1f lanes without a ray, %.1f holding two leaves, %.1f with leaves only; per leaf phase %.1f without a ray, %.1f walkers waiting; %llu refills of %.1f lanes\n",
+						 (double)s->hStats[12] / wi, (double)s->hStats[13] / wi, (double)s->hStats[14] / wi, (double)s->hStats[15] / li, (double)s->hStats[16] / li,
+						 s->hStats[17], (double)s->hStats[18] / (double)std::max(1ull, s->hStats[17]));
 			std::fprintf(stderr, "[rtx] wide: most node visits of one ray %llu, rays over 100: %llu, over 300: %llu\n", s->hStats[9], s->hStats[10], s->hStats[11]);
 		}
 		s->stats.wide_visits = s->hStats[4];
@@ -929,7 +934,7 @@ int finish_stats(rtx_scene* s) {
 int begin_call(rtx_scene* s) {
 	std::memset(&s->stats, 0, sizeof(s->stats));
 	drop_events(s);  // pairs an earlier call left behind when it failed half-way
-	if (s->instrumented) HIPCHK(hipMemsetAsync(s->dStats.p, 0, 12 * sizeof(unsigned long long), s->stream));
+	if (s->instrumented) HIPCHK(hipMemsetAsync(s->dStats.p, 0, STATS_WORDS * sizeof(unsigned long long), s->stream));
 	return RTX_OK;
 }
 
