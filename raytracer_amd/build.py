@@ -11,7 +11,8 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-HIP_SO = os.path.join(PKG, "librtx_hip.so")
+# RTX_HIP_SO names another build of the device library (experiments, -DRTX_BOUNDS_CHECK builds); unset: the product's
+HIP_SO = os.environ.get("RTX_HIP_SO") or os.path.join(PKG, "librtx_hip.so")
 HOST_SO = os.path.join(PKG, "librtx_host.so")
 CLI_BIN = os.path.join(PKG, "RayTracer")
 

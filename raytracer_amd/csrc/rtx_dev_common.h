@@ -32,6 +32,8 @@ struct DevScene {
 	const float4* pairs;     // 4 x float4 per child pair: Lmin|codeL, Lmax|-, Rmin|codeR, Rmax|-
 	const float4* wide;      // 4 x float4 per node of the 4-wide quantised collapse of the tree
 	const float4* triHit;    // 4 x float4 per triangle in candidate-rank order: n, v0, v1, v2, index
+	const float4* triWide;   // the same records in the order of the wide tree's leaves (a leaf's two triangles side by
+	                         // side), fourth quad: index, rank, -, -
 	const float4* triShade;  // 8 x float4 (one 128-byte line) per triangle in candidate-rank order:
 	                         // n0 r | n1 g | n2 b | rough ior tex flags | uv0 uv1 | uv2 - - | - | -
 	const uint8_t* texels;

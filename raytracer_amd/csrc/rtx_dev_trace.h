@@ -353,6 +353,33 @@ constexpr float WIDE_MAX_INV = 1.2676506e30f;  // 2^100
 
 __device__ __forceinline__ float ubyte_f(unsigned v, int k) { return (float)((v >> (8 * k)) & 0xFFu); }
 
+// One triangle of a leaf of the wide tree: the reference's slab predicate on the triangle's own box (src/BVH.cpp:14-41;
+// lane 0 is never NaN where this returns 1 or 0, and fmaxf/fminf skip a NaN in lanes 1 and 2 as the reference's
+// folds do), then Triangle::hit.  T: the triangle's record in sc.triWide.  Returns 1 when the triangle was accepted
+// (best updated), 0 when not, 2 when the origin lies on an x plane of the box and the ray runs along it: the
+// reference accepts such a box whatever y and z say (NaN in lane 0), provided it gets there, which only its own
+// tree can tell.
+template <bool STATS>
+__device__ __forceinline__ int wide_leaf_test(const float4* __restrict__ T, const RaySlab& r, float dx, float dy, float dz, HitState& best,
+											  unsigned& boxTests, unsigned& triTests) {
+	const float4 q0 = T[0], q1 = T[1], q2 = T[2];
+	const int rank = __float_as_int(T[3].y);
+	const float v0x = q0.w, v0y = q1.x, v0z = q1.y, v1x = q1.z, v1y = q1.w, v1z = q2.x, v2x = q2.y, v2y = q2.z, v2z = q2.w;
+	const float lx = fminf(fminf(v0x, v1x), v2x), hx = fmaxf(fmaxf(v0x, v1x), v2x);
+	const float ly = fminf(fminf(v0y, v1y), v2y), hy = fmaxf(fmaxf(v0y, v1y), v2y);
+	const float lz = fminf(fminf(v0z, v1z), v2z), hz = fmaxf(fmaxf(v0z, v1z), v2z);
+	const float t0x = (lx - r.ox) * r.ix, t1x = (hx - r.ox) * r.ix;
+	const float t0y = (ly - r.oy) * r.iy, t1y = (hy - r.oy) * r.iy;
+	const float t0z = (lz - r.oz) * r.iz, t1z = (hz - r.oz) * r.iz;
+	const float tmin = fmaxf(fmaxf(r.nx ? t1x : t0x, r.ny ? t1y : t0y), r.nz ? t1z : t0z);
+	const float tmax = fminf(fminf(r.nx ? t0x : t1x, r.ny ? t0y : t1y), r.nz ? t0z : t1z);
+	if (STATS) boxTests++;
+	if (t0x != t0x || t1x != t1x) return 2;
+	if (tmax < tmin) return 0;
+	if (STATS) triTests++;
+	return tri_test_vals(q0.x, q0.y, q0.z, v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z, rank, r.ox, r.oy, r.oz, dx, dy, dz, best) ? 1 : 0;
+}
+
 template <int STACK, bool ANYHIT, bool STATS>
 __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_trace_wide(DevScene sc, const float4* __restrict__ rayO,
 															   const float4* __restrict__ rayD, float4* __restrict__ hits,
@@ -361,7 +388,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 															   unsigned* __restrict__ unsafeCount, int refill, int chunk,
 															   int triBatch, const unsigned* __restrict__ nDev,
 															   int* __restrict__ longList, unsigned* __restrict__ longCount, int longVisits,
-															   int smallQueue) {
+															   int smallQueue, int tailVisits) {
 	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
 	// A queue of a few thousand rays cannot fill the chip with one ray per lane; its launch would last as long as
 	// its longest ray walked by a single lane.  All its rays go to k_trace_long, a wave each, at once.
@@ -413,6 +440,9 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 				if (base >= (unsigned)n) {
 					more = false;
 					cnext = cend = 0;
+					// The queue is exhausted: from here on the launch lasts as long as this wave's slowest ray.  Rays
+					// that still have a long way to go move to the wave-per-ray kernel sooner than they otherwise would.
+					visitsLeft = min(visitsLeft, tailVisits);
 				}
 				else {
 					cnext = (int)base;
@@ -505,46 +535,41 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 			}
 		}
 		if (leafPhase) {
-			// exact box of the triangle, exact slab predicate, exact triangle test; one leaf per lane and pass
+			// A leaf is one triangle or two that share a box (value = first record * 2 + 1 if there is a second): each is
+			// tested on its own, exact box, exact slab predicate, exact triangle test; one leaf per lane and pass.
 #ifdef RTX_BOUNDS_CHECK
-			if (busy && pend0 >= 0 && (unsigned)pend0 >= (unsigned)sc.nTris) {
-				printf("[rtx] k_trace_wide: leaf %d of %d (ray %d, sp %d, cur %d, pend1 %d)\n", pend0, sc.nTris, j, sp, cur, pend1);
+			if (busy && pend0 >= 0 && (unsigned)((pend0 >> 1) + (pend0 & 1)) >= (unsigned)sc.nTris) {
+				printf("[rtx] k_trace_wide: leaf record %d (+%d) of %d (ray %d, sp %d, cur %d, pend1 %d)\n", pend0 >> 1, pend0 & 1, sc.nTris, j, sp, cur, pend1);
 				atomicOr(sc.fault, FAULT_LEAF);
 				pend0 = pend1 = -1; cur = -1; sp = 0;
 			}
 #endif
+			bool todo = busy && pend0 >= 0;
+			const float4* T = sc.triWide + (size_t)(todo ? (pend0 >> 1) : 0) * 4;
+			const bool second = todo && (pend0 & 1) != 0;
+			for (int k = 0; k < 2; ++k) {
+				if (todo) {
+					if (STATS) leafFetches++;
+					const int res = wide_leaf_test<STATS>(T, r, dx, dy, dz, best, boxTests, triTests);
+					if (res == 2) {
+						// the ray starts over in the binary-tree kernel
+						unsafeList[atomicAdd(unsafeCount, 1u)] = j;
+						busy = false;
+						cur = -1;
+						sp = 0;
+						pend0 = pend1 = -1;
+						todo = false;
+					}
+					else if (res == 1) {
+						found = true;
+						if (ANYHIT) todo = false;
+					}
+				}
+				todo = todo && second;
+				if (k == 1 || __builtin_amdgcn_ballot_w64(todo) == 0ull) break;
+				T += 4;
+			}
 			if (busy && pend0 >= 0) {
-				const float4* T = sc.triHit + (size_t)pend0 * 4;
-				float4 q0 = T[0], q1 = T[1], q2 = T[2];
-				if (STATS) leafFetches++;
-				const float v0x = q0.w, v0y = q1.x, v0z = q1.y, v1x = q1.z, v1y = q1.w, v1z = q2.x, v2x = q2.y, v2y = q2.z, v2z = q2.w;
-				// the reference's predicate on the leaf's own box (src/BVH.cpp:14-41); lane 0 is never NaN here and
-				// fmaxf/fminf skip a NaN in lanes 1 and 2 as the reference's folds do
-				const float lx = fminf(fminf(v0x, v1x), v2x), hx = fmaxf(fmaxf(v0x, v1x), v2x);
-				const float ly = fminf(fminf(v0y, v1y), v2y), hy = fmaxf(fmaxf(v0y, v1y), v2y);
-				const float lz = fminf(fminf(v0z, v1z), v2z), hz = fmaxf(fmaxf(v0z, v1z), v2z);
-				const float t0x = (lx - r.ox) * r.ix, t1x = (hx - r.ox) * r.ix;
-				const float t0y = (ly - r.oy) * r.iy, t1y = (hy - r.oy) * r.iy;
-				const float t0z = (lz - r.oz) * r.iz, t1z = (hz - r.oz) * r.iz;
-				const float tmin = fmaxf(fmaxf(r.nx ? t1x : t0x, r.ny ? t1y : t0y), r.nz ? t1z : t0z);
-				const float tmax = fminf(fminf(r.nx ? t0x : t1x, r.ny ? t0y : t1y), r.nz ? t0z : t1z);
-				const bool pass = !(tmax < tmin);
-				if (STATS) boxTests++;
-				if (t0x != t0x || t1x != t1x) {
-					// The origin lies on an x plane of this box and the ray runs along it: the reference accepts
-					// such a box whatever y and z say (NaN in lane 0), provided it gets there, which only its own
-					// tree can tell.  The ray starts over in the binary-tree kernel.
-					unsafeList[atomicAdd(unsafeCount, 1u)] = j;
-					busy = false;
-					cur = -1;
-					sp = 0;
-					pend1 = -1;
-				}
-				else if (pass) {
-					if (STATS) triTests++;
-					found |= tri_test_vals(q0.x, q0.y, q0.z, v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z, pend0, r.ox, r.oy,
-										   r.oz, dx, dy, dz, best);
-				}
 				pend0 = pend1;
 				pend1 = -1;
 				if (ANYHIT && found) {
@@ -601,7 +626,9 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 					float x = fminf(fminf(__fmaf_rn(ubyte_f(fxd, c), Sx, Afx), __fmaf_rn(ubyte_f(fyd, c), Sy, Afy)),
 									__fmaf_rn(ubyte_f(fzd, c), Sz, Afz));
 					e = fmaxf(e, 0.001f);
-					const bool h = (cd[c] != 0) & !(x < e) & !(e > best.t);
+					// an absent child is an empty interval on every axis (lo 255, hi 0), which the slack can reopen only in a
+					// node a few slacks wide; its code is 0, and an item 0 is skipped wherever items are taken up
+					const bool h = !(x < e) & !(e > best.t);
 					// closest hit: nearest child first.  Any hit: the child the ray stays in longest first, where an
 					// occluder is likeliest (any order gives the same answer; the key stays below the "not
 					// entered" marker because the length is clamped to >= +0).
@@ -716,7 +743,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 // A ray whose stack would overflow, or that meets the NaN-in-lane-0 case at a leaf, goes on to the set-aside
 // list of the binary-tree kernel, which runs after this one.
 constexpr int LONG_STACK = 1024;     // open nodes per ray
-constexpr int LONG_LEAVES = 128;     // >= 64 (the trigger) + 64 (one step's yield)
+constexpr int LONG_LEAVES = 192;     // >= 63 (below the trigger) + 128 (one step's yield: 64 leaves of two triangles)
 
 template <bool ANYHIT, bool STATS>
 __global__ __launch_bounds__(TRACE_THREADS) void k_trace_long(DevScene sc, const float4* __restrict__ rayO,
@@ -784,24 +811,11 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_long(DevScene sc, const
 				HitState cand = best;
 				bool nanX = false;
 				if ((int)lane < take) {
-					const int rank = lf[nLeaf + (int)lane];
-					const float4* T = sc.triHit + (size_t)rank * 4;
-					const float4 q0 = T[0], q1 = T[1], q2 = T[2];
-					const float v0x = q0.w, v0y = q1.x, v0z = q1.y, v1x = q1.z, v1y = q1.w, v1z = q2.x, v2x = q2.y, v2y = q2.z, v2z = q2.w;
-					const float lx = fminf(fminf(v0x, v1x), v2x), hx = fmaxf(fmaxf(v0x, v1x), v2x);
-					const float ly = fminf(fminf(v0y, v1y), v2y), hy = fmaxf(fmaxf(v0y, v1y), v2y);
-					const float lz = fminf(fminf(v0z, v1z), v2z), hz = fmaxf(fmaxf(v0z, v1z), v2z);
-					const float t0x = (lx - r.ox) * r.ix, t1x = (hx - r.ox) * r.ix;
-					const float t0y = (ly - r.oy) * r.iy, t1y = (hy - r.oy) * r.iy;
-					const float t0z = (lz - r.oz) * r.iz, t1z = (hz - r.oz) * r.iz;
-					const float tmin = fmaxf(fmaxf(r.nx ? t1x : t0x, r.ny ? t1y : t0y), r.nz ? t1z : t0z);
-					const float tmax = fminf(fminf(r.nx ? t0x : t1x, r.ny ? t0y : t1y), r.nz ? t0z : t1z);
-					nanX = t0x != t0x || t1x != t1x;
-					if (!nanX && !(tmax < tmin)) {
-						if (tri_test_vals(q0.x, q0.y, q0.z, v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z, rank, r.ox, r.oy, r.oz,
-										  dx, dy, dz, cand))
-							key = ((unsigned long long)__float_as_uint(cand.t) << 32) | (unsigned)cand.rank;
-					}
+					const int rec = lf[nLeaf + (int)lane];  // a record of sc.triWide: one triangle
+					unsigned bt = 0, tt = 0;
+					const int res = wide_leaf_test<false>(sc.triWide + (size_t)rec * 4, r, dx, dy, dz, cand, bt, tt);
+					nanX = res == 2;
+					if (res == 1) key = ((unsigned long long)__float_as_uint(cand.t) << 32) | (unsigned)cand.rank;
 				}
 				if (STATS) { leafFetches += take; boxTests += take; triTests += take; }
 				if (__builtin_amdgcn_ballot_w64(nanX) != 0ull) {
@@ -861,9 +875,27 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_long(DevScene sc, const
 				break;
 			}
 			if (h && code > 0) stk[nStk + __popcll(mNode & below)] = code;
-			if (h && code < 0) lf[nLeaf + __popcll(mLeaf & below)] = ~code;
+			// a leaf is one record of sc.triWide or two consecutive ones (value = first record * 2 + 1 if two): the list
+			// takes them apart, one triangle per entry
+			const bool two = h && code < 0 && ((~code) & 1) != 0;
+			const unsigned long long mTwo = __builtin_amdgcn_ballot_w64(two);
+			if (h && code < 0) {
+				const int at = nLeaf + __popcll(mLeaf & below) + __popcll(mTwo & below);
+				const int rec = (~code) >> 1;
+#ifdef RTX_BOUNDS_CHECK
+				if ((unsigned)(rec + (two ? 1 : 0)) >= (unsigned)sc.nTris || at + 1 >= LONG_LEAVES) {
+					printf("[rtx] k_trace_long: leaf record %d of %d at list slot %d\n", rec, sc.nTris, at);
+					atomicOr(sc.fault, FAULT_LEAF);
+				}
+				else
+#endif
+				{
+					lf[at] = rec;
+					if (two) lf[at + 1] = rec + 1;
+				}
+			}
 			nStk += __popcll(mNode);
-			nLeaf += __popcll(mLeaf);
+			nLeaf += __popcll(mLeaf) + __popcll(mTwo);
 			__builtin_amdgcn_wave_barrier();  // the next round's lanes read what other lanes have just written
 		}
 		if (aside) {

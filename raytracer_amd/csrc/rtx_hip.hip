@@ -171,8 +171,9 @@ struct rtx_scene {
 	int longBlocksPerCU = 8;         // grid of k_trace_long (RTX_LONG_BLOCKS)
 	int smallQueueFactor = 16;       // queues of up to this many rays per wave of k_trace_long go there entirely (RTX_SMALL_QUEUE)
 	int longVisits = 64;             // nodes one lane walks for a ray before a whole wave takes the ray over (RTX_LONG_VISITS, 0 = never)
+	int tailVisits = 32;             // the same allowance for rays still in flight once a wave finds the queue exhausted (RTX_TAIL_VISITS)
 	long long mergeBlocks = 131072;  // frames of a multi-frame call share a batch up to this many 4x4-pixel blocks (RTX_MERGE_BLOCKS)
-	int traceRefill = TRACE_REFILL, traceChunk = TRACE_CHUNK, traceBlocksPerCU = 6, traceTriBatch = 24;  // tunables (RTX_TRACE_* env)
+	int traceRefill = TRACE_REFILL, traceChunk = TRACE_CHUNK, traceBlocksPerCU = 6, traceTriBatch = 28;  // tunables (RTX_TRACE_* env)
 	hipStream_t stream = nullptr;
 	hipStream_t ownStream = nullptr;
 	// parameters
@@ -212,7 +213,7 @@ struct rtx_scene {
 	uint32_t numWide = 0;
 	uint32_t numPairs = 0;
 	// device
-	DevBuf<float4> dPairs, dWide, dTriHit, dTriShade;
+	DevBuf<float4> dPairs, dWide, dTriHit, dTriWide, dTriShade;
 	DevBuf<unsigned> dToneBits;
 	DevBuf<unsigned char> dToneVal, dRgb8;
 	int toneN = 0;
@@ -238,7 +239,7 @@ struct rtx_scene {
 
 	~rtx_scene() {
 		(void)hipSetDevice(device);
-		dPairs.release(); dWide.release(); dTriHit.release(); dTriShade.release(); dToneBits.release(); dToneVal.release(); dRgb8.release(); dTexels.release(); dTexDesc.release();
+		dPairs.release(); dWide.release(); dTriHit.release(); dTriWide.release(); dTriShade.release(); dToneBits.release(); dToneVal.release(); dRgb8.release(); dTexels.release(); dTexDesc.release();
 		dTables.release(); dAccumOwn.release(); dTilePack.release(); dTileRecv.release(); arena.release(); dCounts.release(); dStats.release();
 		if (hCounts) (void)hipHostFree(hCounts);
 		if (hStats) (void)hipHostFree(hStats);
@@ -299,6 +300,7 @@ DevScene make_dev_scene(const rtx_scene* s) {
 	d.pairs = s->dPairs.p;
 	d.wide = s->dWide.p;
 	d.triHit = s->dTriHit.p;
+	d.triWide = s->dTriWide.p;
 	d.triShade = s->dTriShade.p;
 	d.texels = s->dTexels.p;
 	d.texDesc = s->dTexDesc.p;
@@ -508,7 +510,8 @@ int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float
 #define RTX_LAUNCH(STK, ST)                                                                                              \
 	hipLaunchKernelGGL((k_trace_wide<STK, ANYHIT, ST>), grid, block, 0, s->stream, d, ro, rd, hits, n, stats, work,      \
 					   unsafeList, unsafeCount, s->traceRefill, s->traceChunk, s->traceTriBatch, nDev, longList, longCount, \
-					   s->longVisits, s->longVisits == INT_MAX ? -1 : s->numCUs * s->longBlocksPerCU * (TRACE_THREADS / 64) * s->smallQueueFactor)
+					   s->longVisits, s->longVisits == INT_MAX ? -1 : s->numCUs * s->longBlocksPerCU * (TRACE_THREADS / 64) * s->smallQueueFactor, \
+					   s->longVisits == INT_MAX ? INT_MAX : s->tailVisits)
 	if (need <= 16) {
 		if (st) RTX_LAUNCH(16, true); else RTX_LAUNCH(16, false);
 	}
@@ -974,6 +977,7 @@ RTX_API int rtx_scene_create(rtx_scene** out, int device) {
 	if (const char* e = std::getenv("RTX_LONG_BLOCKS")) s->longBlocksPerCU = std::max(1, std::min(8, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_SMALL_QUEUE")) s->smallQueueFactor = std::max(0, std::atoi(e));
 	if (const char* e = std::getenv("RTX_LONG_VISITS")) s->longVisits = std::atoi(e) > 0 ? std::atoi(e) : INT_MAX;
+	if (const char* e = std::getenv("RTX_TAIL_VISITS")) s->tailVisits = std::max(0, std::atoi(e));
 	if (const char* e = std::getenv("RTX_MERGE_BLOCKS")) s->mergeBlocks = std::max(1ll, std::atoll(e));
 	if (const char* e = std::getenv("RTX_TRACE_TRI_BATCH")) s->traceTriBatch = std::max(1, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_TRACE_BLOCKS_PER_CU")) s->traceBlocksPerCU = std::max(1, std::atoi(e));
@@ -1185,27 +1189,61 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 	}
 	lap("premise check");
 	std::vector<float> wide;
+	std::vector<int> recTri;  // triangle of every leaf record of the wide tree, in the order the records are stored
 	int wideStackNeed = 1;
+	size_t pairedLeaves = 0;
 	const char* treeKind = "none";
 	if (wideOk) {
 		// own surface-area tree over the triangles' boxes; the reference's tree if that one cannot be used
 		bool built = false;
 		const char* want = std::getenv("RTX_WIDE_TREE");
 		if (!(want && std::strcmp(want, "reference") == 0)) {
-			std::vector<float> box((size_t)ntri * 6);
+			std::vector<float> box((size_t)ntri * 6), verts((size_t)ntri * 9);
 			for (uint32_t i = 0; i < ntri; ++i) {
 				const HostTri& t = s->tris[i];
 				for (int c = 0; c < 3; ++c) {
 					box[(size_t)i * 6 + c] = std::min(std::min(t.v[0][c], t.v[1][c]), t.v[2][c]);
 					box[(size_t)i * 6 + 3 + c] = std::max(std::max(t.v[0][c], t.v[1][c]), t.v[2][c]);
+					for (int k = 0; k < 3; ++k) verts[(size_t)i * 9 + k * 3 + c] = t.v[k][c];
 				}
 			}
-			std::vector<rtxwide::BinNode> own;
 			const int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 			lap("triangle boxes");
-			rtxwide::build_sah(box, (int)ntri, own, threads);
+			// leaves: pairs of triangles that share an edge and a box (RTX_LEAF_PAIRS=0: one triangle each)
+			std::vector<int> mate(ntri, -1);
+			const char* lp = std::getenv("RTX_LEAF_PAIRS");
+			if (!(lp && std::atoi(lp) == 0)) rtxwide::pair_triangles(verts.data(), box, (int)ntri, mate, threads);
+			lap("leaf pairs");
+			std::vector<float> primBox;
+			std::vector<int> leafValue;
+			primBox.reserve((size_t)ntri * 6);
+			recTri.reserve(ntri);
+			for (uint32_t i = 0; i < ntri; ++i) {
+				const int m = mate[i];
+				if (m >= 0 && (uint32_t)m < i) continue;  // emitted with its mate
+				const size_t rec = recTri.size();
+				float b6[6];
+				std::memcpy(b6, &box[(size_t)i * 6], sizeof(b6));
+				if (m >= 0) {
+					for (int c = 0; c < 3; ++c) {
+						b6[c] = std::min(b6[c], box[(size_t)m * 6 + c]);
+						b6[3 + c] = std::max(b6[3 + c], box[(size_t)m * 6 + 3 + c]);
+					}
+					// the triangle the reference would come to first stands first
+					const bool iFirst = rankOf[i] < rankOf[m];
+					recTri.push_back(iFirst ? (int)i : m);
+					recTri.push_back(iFirst ? m : (int)i);
+					++pairedLeaves;
+				}
+				else
+					recTri.push_back((int)i);
+				primBox.insert(primBox.end(), b6, b6 + 6);
+				leafValue.push_back((int)(rec * 2 + (m >= 0 ? 1 : 0)));
+			}
+			std::vector<rtxwide::BinNode> own;
+			rtxwide::build_sah(primBox, (int)leafValue.size(), own, threads);
 			lap("surface-area tree");
-			built = rtxwide::collapse_wide(own, rankOf, wide, wideStackNeed, threads);
+			built = rtxwide::collapse_wide(own, leafValue, wide, wideStackNeed, threads);
 			lap("4-wide collapse + quantise");
 			treeKind = "surface-area";
 		}
@@ -1218,15 +1256,23 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 				ref[i].right = N[i].right > 0 ? N[i].right : -1;
 				ref[i].tri = N[i].tri >= 0 ? N[i].tri : -1;
 			}
-			built = rtxwide::collapse_wide(ref, rankOf, wide, wideStackNeed);
+			// one triangle per leaf, records in rank order
+			std::vector<int> leafValue(ntri);
+			recTri.assign(ntri, 0);
+			pairedLeaves = 0;
+			for (uint32_t i = 0; i < ntri; ++i) {
+				leafValue[i] = rankOf[i] * 2;
+				recTri[(size_t)rankOf[i]] = (int)i;
+			}
+			built = rtxwide::collapse_wide(ref, leafValue, wide, wideStackNeed);
 			treeKind = "reference";
 		}
 		wideOk = built;
 	}
 
 	if (std::getenv("RTX_TRACE_DEBUG"))
-		std::fprintf(stderr, "[rtx] wide tree (%s): ok %d, %zu nodes, stack need %d (binary: %zu pairs, stack need %d)\n", treeKind,
-					 (int)wideOk, wide.size() / 16, wideStackNeed, npairs, maxInteriorDepth + 1);
+		std::fprintf(stderr, "[rtx] wide tree (%s): ok %d, %zu nodes, %zu of %u triangles in two-triangle leaves, stack need %d (binary: %zu pairs, stack need %d)\n", treeKind,
+					 (int)wideOk, wide.size() / 16, pairedLeaves * 2, ntri, wideStackNeed, npairs, maxInteriorDepth + 1);
 
 	lap("-");
 	// Triangle records in rank order.
@@ -1261,6 +1307,22 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 		ts[r * 8 + 5] = make_float4(t.uv[2][0], t.uv[2][1], 0.0f, 0.0f);
 	}
 
+	// The same hit records once more in the order of the wide tree's leaves (the two triangles of a leaf side by
+	// side), each with its rank in the fourth quad: what k_trace_wide and k_trace_long read.
+	std::vector<float4> tw;
+	if (wideOk) {
+		tw.resize((size_t)std::max<uint32_t>(ntri, 1) * 4);
+		for (size_t rec = 0; rec < recTri.size(); ++rec) {
+			const size_t r = (size_t)rankOf[recTri[rec]];
+			tw[rec * 4 + 0] = th[r * 4 + 0];
+			tw[rec * 4 + 1] = th[r * 4 + 1];
+			tw[rec * 4 + 2] = th[r * 4 + 2];
+			float rankf;
+			const int32_t ri = (int32_t)r;
+			std::memcpy(&rankf, &ri, 4);
+			tw[rec * 4 + 3] = make_float4(th[r * 4 + 3].x, rankf, 0.0f, 0.0f);
+		}
+	}
 	lap("triangle records");
 	HIPCHK(hipSetDevice(s->device));
 	HIPCHK(s->dPairs.alloc(pairs.size()));
@@ -1268,6 +1330,8 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 	if (wideOk) {
 		HIPCHK(s->dWide.alloc(wide.size() / 4));
 		HIPCHK(hipMemcpy(s->dWide.p, wide.data(), wide.size() * sizeof(float), hipMemcpyHostToDevice));
+		HIPCHK(s->dTriWide.alloc(tw.size()));
+		HIPCHK(hipMemcpy(s->dTriWide.p, tw.data(), tw.size() * sizeof(float4), hipMemcpyHostToDevice));
 	}
 	s->wideOk = wideOk;
 	s->wideStackNeed = wideStackNeed;

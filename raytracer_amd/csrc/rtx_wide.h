@@ -208,15 +208,160 @@ inline void build_sah(const std::vector<float>& box, int ntri, std::vector<BinNo
 	}
 }
 
+// Leaves of two triangles.  Two triangles that share an edge and whose common box is hardly larger than the larger
+// of their own boxes (the two halves of a quad of a tessellated surface: for an axis-aligned quad both boxes ARE the
+// common box) are walked as one leaf: the tree over n/2 such leaves is about a level shallower, and a ray that
+// reaches the quad parks one leaf instead of two.  The kernels still test each triangle of a leaf on its own (own
+// box, own Triangle::hit), so what is found is unchanged.
+// mate[i] = the triangle paired with i, or -1.  Shared edges are found by sorting the 3n edges by a hash of their end
+// points (order-independent) and comparing the end points of equal hashes bit for bit.  Pairs are taken greedily in
+// index order, the tightest class first (common box within 2 % of the larger own box), then up to maxGrowth.
+inline void pair_triangles(const float* verts9, const std::vector<float>& box, int ntri, std::vector<int>& mate, int nthreads,
+						   double maxGrowth = 1.3) {
+	mate.assign((size_t)ntri, -1);
+	if (ntri < 2) return;
+	struct Edge {
+		uint64_t key;
+		int tri, e;
+	};
+	auto mix64 = [](uint64_t h, uint32_t v) {
+		h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+		h *= 0xFF51AFD7ED558CCDull;
+		h ^= h >> 33;
+		return h;
+	};
+	auto vhash = [&](const float* p) {
+		uint32_t u[3];
+		std::memcpy(u, p, 12);
+		for (uint32_t& w : u)
+			if (w == 0x80000000u) w = 0;  // -0 and +0 are the same point
+		return mix64(mix64(mix64(0x1234567ull, u[0]), u[1]), u[2]);
+	};
+	std::vector<Edge> edges((size_t)ntri * 3);
+	auto fill = [&](int t0, int t1) {
+		for (int t = t0; t < t1; ++t) {
+			const float* v = verts9 + (size_t)t * 9;
+			const uint64_t h[3] = {vhash(v), vhash(v + 3), vhash(v + 6)};
+			for (int e = 0; e < 3; ++e) {
+				const uint64_t a = h[e], b = h[(e + 1) % 3];
+				edges[(size_t)t * 3 + e] = Edge{std::min(a, b) * 0x9E3779B97F4A7C15ull + std::max(a, b), t, e};
+			}
+		}
+	};
+	const int T = std::max(1, std::min(nthreads, ntri / 65536 + 1));
+	{
+		std::vector<std::thread> th;
+		for (int k = 0; k < T; ++k) th.emplace_back(fill, (int)((long long)ntri * k / T), (int)((long long)ntri * (k + 1) / T));
+		for (auto& t : th) t.join();
+	}
+	// sort by key: buckets by the top bits (serial counting pass), each bucket sorted on a thread of its own
+	constexpr int BUCKET_BITS = 6, NB = 1 << BUCKET_BITS;
+	std::vector<size_t> start(NB + 1, 0);
+	for (const Edge& e : edges) start[(e.key >> (64 - BUCKET_BITS)) + 1]++;
+	for (int b = 0; b < NB; ++b) start[b + 1] += start[b];
+	std::vector<Edge> sorted(edges.size());
+	{
+		std::vector<size_t> pos(start.begin(), start.end() - 1);
+		for (const Edge& e : edges) sorted[pos[e.key >> (64 - BUCKET_BITS)]++] = e;
+	}
+	edges.clear();
+	edges.shrink_to_fit();
+	auto by_key = [](const Edge& a, const Edge& b) { return a.key != b.key ? a.key < b.key : a.tri != b.tri ? a.tri < b.tri : a.e < b.e; };
+	{
+		std::atomic<int> next(0);
+		auto work = [&] {
+			for (;;) {
+				const int b = next.fetch_add(1);
+				if (b >= NB) break;
+				std::sort(sorted.begin() + start[b], sorted.begin() + start[b + 1], by_key);
+			}
+		};
+		std::vector<std::thread> th;
+		for (int k = 0; k < T; ++k) th.emplace_back(work);
+		for (auto& t : th) t.join();
+	}
+	auto same_point = [](const float* a, const float* b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2]; };
+	auto same_edge = [&](const Edge& x, const Edge& y) {
+		const float* vx = verts9 + (size_t)x.tri * 9;
+		const float* vy = verts9 + (size_t)y.tri * 9;
+		const float *a0 = vx + 3 * x.e, *a1 = vx + 3 * ((x.e + 1) % 3), *b0 = vy + 3 * y.e, *b1 = vy + 3 * ((y.e + 1) % 3);
+		return (same_point(a0, b0) && same_point(a1, b1)) || (same_point(a0, b1) && same_point(a1, b0));
+	};
+	auto growth = [&](int i, int j) {
+		float mn[3], mx[3];
+		for (int a = 0; a < 3; ++a) {
+			mn[a] = std::min(box[(size_t)i * 6 + a], box[(size_t)j * 6 + a]);
+			mx[a] = std::max(box[(size_t)i * 6 + 3 + a], box[(size_t)j * 6 + 3 + a]);
+		}
+		const double own = std::max(half_area(&box[(size_t)i * 6], &box[(size_t)i * 6 + 3]), half_area(&box[(size_t)j * 6], &box[(size_t)j * 6 + 3]));
+		const double both = half_area(mn, mx);
+		return own > 0.0 ? both / own : (both > 0.0 ? DBL_MAX : 1.0);
+	};
+	// every edge gets the triangle on its other side (the tightest one if there are several), bucket by bucket on the
+	// threads: the slots written belong to the edges of the bucket
+	std::vector<int> other((size_t)ntri * 3, -1);
+	std::vector<float> otherGrowth((size_t)ntri * 3, FLT_MAX);
+	{
+		std::atomic<int> next(0);
+		auto work = [&] {
+			for (;;) {
+				const int bkt = next.fetch_add(1);
+				if (bkt >= NB) break;
+				for (size_t a = start[bkt]; a < start[bkt + 1];) {
+					size_t b = a + 1;
+					while (b < start[bkt + 1] && sorted[b].key == sorted[a].key) ++b;
+					if (b - a <= 8)  // an edge shared by more triangles than that is no surface
+						for (size_t x = a; x < b; ++x)
+							for (size_t y = a; y < b; ++y)
+								if (sorted[x].tri != sorted[y].tri && same_edge(sorted[x], sorted[y])) {
+									const double g = growth(sorted[x].tri, sorted[y].tri);
+									const size_t slot = (size_t)sorted[x].tri * 3 + sorted[x].e;
+									if (g <= maxGrowth && ((float)g < otherGrowth[slot] || ((float)g == otherGrowth[slot] && sorted[y].tri < other[slot]))) {
+										otherGrowth[slot] = (float)g;
+										other[slot] = sorted[y].tri;
+									}
+								}
+					a = b;
+				}
+			}
+		};
+		std::vector<std::thread> th;
+		for (int k = 0; k < T; ++k) th.emplace_back(work);
+		for (auto& t : th) t.join();
+	}
+	// greedy, in index order: a free triangle takes the free neighbour with which it shares the tightest box
+	for (int pass = 0; pass < 2; ++pass) {
+		const float limit = pass == 0 ? 1.02f : (float)maxGrowth;
+		for (int i = 0; i < ntri; ++i) {
+			if (mate[i] >= 0) continue;
+			int pick = -1;
+			float g = FLT_MAX;
+			for (int e = 0; e < 3; ++e) {
+				const int o = other[(size_t)i * 3 + e];
+				const float og = otherGrowth[(size_t)i * 3 + e];
+				if (o < 0 || mate[o] >= 0 || og > limit) continue;
+				if (og < g || (og == g && o < pick)) {
+					g = og;
+					pick = o;
+				}
+			}
+			if (pick >= 0) {
+				mate[i] = pick;
+				mate[pick] = i;
+			}
+		}
+	}
+}
+
 // Collapses a binary tree four wide and quantises it.  out: 16 floats per wide node,
 //   px py pz sx                          origin; sx, sy, sz: quantisation steps (powers of two)
 //   lo.x[4] hi.x[4] lo.y[4] hi.y[4]      one byte per child
 //   lo.z[4] hi.z[4] code0 code1
-//   code2 code3 sy sz                      code > 0 wide node, < 0 ~rank of a triangle, 0 absent
+//   code2 code3 sy sz                      code > 0 wide node, < 0 ~leafValue[N[.].tri] (a leaf), 0 absent
 // A node's children are found by opening, largest surface first, the interior children of the binary
 // node until there are four.  stackNeed: entries a traversal may have waiting when it takes the nearest
 // child directly and stacks the others.  Returns false when a box cannot be represented.
-inline bool collapse_wide(const std::vector<BinNode>& N, const std::vector<int>& rankOf, std::vector<float>& out, int& stackNeed,
+inline bool collapse_wide(const std::vector<BinNode>& N, const std::vector<int>& leafValue, std::vector<float>& out, int& stackNeed,
 						  int nthreads = 1) {
 	auto interior = [&](int i) { return N[i].tri < 0 && (N[i].left >= 0 || N[i].right >= 0); };
 	auto usable = [&](int i) { return i >= 0 && (N[i].tri >= 0 || interior(i)); };
@@ -318,7 +463,7 @@ inline bool collapse_wide(const std::vector<BinNode>& N, const std::vector<int>&
 				}
 			}
 			int code[4] = {0, 0, 0, 0};
-			for (int c = 0; c < k; ++c) code[c] = N[m[c]].tri >= 0 ? ~rankOf[N[m[c]].tri] : wideOf[m[c]];
+			for (int c = 0; c < k; ++c) code[c] = N[m[c]].tri >= 0 ? ~leafValue[N[m[c]].tri] : wideOf[m[c]];
 			float* w = &out[h * 16];
 			w[0] = (float)lo[0]; w[1] = (float)lo[1]; w[2] = (float)lo[2]; w[3] = steps[0];
 			w[4] = bits(q[0]); w[5] = bits(q[1]); w[6] = bits(q[2]); w[7] = bits(q[3]);

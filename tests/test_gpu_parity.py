@@ -439,6 +439,43 @@ def test_trees_the_wide_kernel_cannot_use_and_short_stacks(libs, monkeypatch):
     assert short.stats()["rays_set_aside"] >= ref.stats()["rays_set_aside"]
 
 
+def test_leaves_of_two_triangles_change_nothing(libs, monkeypatch):
+    """The traversal tree keeps the two halves of a quad (triangles that share an edge and, nearly, a box) in one
+    leaf; each triangle is still tested on its own, so ids, t/alpha/beta, radiance and ray counts must equal those of
+    the tree with one triangle per leaf (RTX_LEAF_PAIRS=0), which in turn equal the CPU restatement's -- while fewer
+    nodes are visited.  Also with nearly every ray forced through the wave-per-ray kernel, which takes the leaves
+    apart again."""
+    sc = scenes.atrium_scene(width=160, height=90, max_depth=3, detail=0.25)
+    nodes = api.build_bvh(sc.tris)
+    O = binding.Oracle()
+    load_into(O, sc, build=False)
+    O.set_nodes(nodes)
+    want = np.zeros((sc.height, sc.width, 4), np.float32)
+    O.reset_counts()
+    O.render_rows(1, want, nthreads=16)
+    got = {}
+    for pairs, visits in (("1", None), ("0", None), ("1", "3")):
+        monkeypatch.setenv("RTX_LEAF_PAIRS", pairs)
+        if visits:
+            monkeypatch.setenv("RTX_LONG_VISITS", visits)
+        rt = api.RayTracer(0)
+        rt.load_scene(sc, nodes)
+        ids, tab = rt.primary_hits(0)
+        rt.set_instrumented(True)
+        rt.reset()
+        rt.render(1, 1)
+        st = rt.stats()
+        assert st["rays"] == O.ray_count()
+        assert_bits_equal(want[..., :3], rt.accum()[..., :3], "accumulator, pairs=%s long=%s" % (pairs, visits))
+        got[(pairs, visits)] = (ids, tab, st["wide_visits"], st["rays_wave_traced"])
+    a, b, c = got[("1", None)], got[("0", None)], got[("1", "3")]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[0], c[0])
+    assert_bits_equal(a[1], b[1], "t/alpha/beta, pairs against single leaves")
+    assert_bits_equal(a[1], c[1], "t/alpha/beta, lane-per-ray against wave-per-ray")
+    assert a[2] < b[2], "two-triangle leaves should visit fewer nodes (%d against %d)" % (a[2], b[2])
+    assert c[3] > 0.2 * O.ray_count()
+
+
 @pytest.mark.parametrize("visits", ["2", "9"])
 def test_long_rays_taken_over_by_a_whole_wave(libs, monkeypatch, visits):
     """A ray that has visited its allowance of nodes in the one-ray-per-lane kernel starts over in the kernel that
