@@ -52,7 +52,10 @@ __device__ __forceinline__ void scatter_offset(const DevScene& sc, uint32_t key,
 	oz = 0.0f * st + ct * 1.0f;
 }
 
-constexpr int SHADE_THREADS = 1024;  // 16 waves share one queue-tail atomic
+#ifndef RTX_SHADE_THREADS
+#define RTX_SHADE_THREADS 1024
+#endif
+constexpr int SHADE_THREADS = RTX_SHADE_THREADS;  // 16 waves share one queue-tail atomic
 
 __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level, const float4* __restrict__ rayO,
 											   const float4* __restrict__ rayD, const float4* __restrict__ hits, int n,

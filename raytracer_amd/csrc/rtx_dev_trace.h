@@ -760,9 +760,13 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace_long(DevScene sc, const
 	int* lf = sLeaf[w];
 	const unsigned count = min(*listCount, (unsigned)capN);  // capN: capacity of the ray arrays and of the list
 	unsigned nodeVisits = 0, leafFetches = 0, boxTests = 0, triTests = 0;  // wave-level, kept uniform
-	// Everything a wave does here is uniform over its lanes, and the code keeps it visibly so: no statement is
-	// guarded by "lane == 0" (all lanes store the same value to the same place instead).  Lanes that skip such a
-	// guard may otherwise be scheduled ahead of lane 0 into the next ballot or shuffle, which then sees half a wave.
+	// Everything a wave does here is uniform over its lanes, and the code keeps it so by construction: the counts of
+	// the two lists are computed by every lane from ballots (never updated by one lane on behalf of the others), no
+	// statement is guarded by "lane == 0" (all lanes store the same value to the same place instead), and every ballot
+	// and shuffle runs under the full wave or under a condition that is the same in all lanes.  The lanes of a wave
+	// share one program counter; what a guarded update of a loop-carried count can do is leave the lanes with different
+	// copies of it, so that they disagree on the loop condition and the next ballot sees part of the wave.  Whatever
+	// the state, the loop below ends: it is bounded by the number of nodes and triangles (maxRounds).
 	const unsigned nWaves = gridDim.x * (TRACE_THREADS / 64);
 	for (unsigned idx = blockIdx.x * (TRACE_THREADS / 64) + (unsigned)w; idx < count; idx += nWaves) {
 		const int j = list[idx];
