@@ -398,6 +398,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 	// last as long as one wave needs for its whole chunk.
 	chunk = min(chunk, max(64, (int)((unsigned)n / (gridDim.x * (TRACE_THREADS / 64) * 3u) + 63u) & ~63));
 	__shared__ int stk[STACK][TRACE_THREADS];
+	__shared__ unsigned char sPool[TRACE_THREADS / 64][128];  // leaf phase: lanes that want help | lanes that help, by rank
 	const int tid = threadIdx.x;
 	const unsigned lane = (unsigned)tid & 63u;
 	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -544,30 +545,79 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 				pend0 = pend1 = -1; cur = -1; sp = 0;
 			}
 #endif
-			bool todo = busy && pend0 >= 0;
-			const float4* T = sc.triWide + (size_t)(todo ? (pend0 >> 1) : 0) * 4;
+			// The second triangle of a leaf is tested at the same time as the first, by a lane that has no leaf of its own
+			// (one without a ray, or a walker waiting for this phase): leaves that want help and lanes that can give it
+			// are matched by their ranks in the two ballots, through a small table in LDS; the helper pulls the ray and
+			// the best hit so far from its partner (ds_bpermute), tests record + 1 against them, and the partner pulls the
+			// outcome back and keeps the better of the two results -- smallest t, lower rank on ties, as if it had tested
+			// the triangles one after the other.  Seconds that found no helper are tested by their own lane afterwards.
+			const bool todo = busy && pend0 >= 0;
 			const bool second = todo && (pend0 & 1) != 0;
-			for (int k = 0; k < 2; ++k) {
-				if (todo) {
-					if (STATS) leafFetches++;
-					const int res = wide_leaf_test<STATS>(T, r, dx, dy, dz, best, boxTests, triTests);
-					if (res == 2) {
-						// the ray starts over in the binary-tree kernel
-						unsafeList[atomicAdd(unsafeCount, 1u)] = j;
-						busy = false;
-						cur = -1;
-						sp = 0;
-						pend0 = pend1 = -1;
-						todo = false;
-					}
-					else if (res == 1) {
+			const unsigned long long mTodo = __builtin_amdgcn_ballot_w64(todo), mSecond = __builtin_amdgcn_ballot_w64(second);
+			const int rankSecond = __popcll(mSecond & below), rankFree = __popcll(~mTodo & below);
+			const int matched = min(__popcll(mSecond), __popcll(~mTodo));
+			const bool helped = second && rankSecond < matched;
+			const bool helper = !todo && rankFree < matched;
+			unsigned char* pool = sPool[tid >> 6];
+			if (helped) pool[rankSecond] = (unsigned char)lane;
+			if (helper) pool[64 + rankFree] = (unsigned char)lane;
+			__builtin_amdgcn_wave_barrier();
+			const int src = helper ? (int)pool[rankFree] : (int)lane;           // whose ray and leaf this lane works on
+			const int back = helped ? (int)pool[64 + rankSecond] : (int)lane;   // who works on this lane's second triangle
+			__builtin_amdgcn_wave_barrier();
+			RaySlab q;
+			q.ox = __shfl(r.ox, src, 64); q.oy = __shfl(r.oy, src, 64); q.oz = __shfl(r.oz, src, 64);
+			q.ix = __shfl(r.ix, src, 64); q.iy = __shfl(r.iy, src, 64); q.iz = __shfl(r.iz, src, 64);
+			q.mx = q.my = q.mz = 0.0f;
+			q.nx = (__float_as_uint(q.ix) >> 31) != 0;
+			q.ny = (__float_as_uint(q.iy) >> 31) != 0;
+			q.nz = (__float_as_uint(q.iz) >> 31) != 0;
+			const float qdx = __shfl(dx, src, 64), qdy = __shfl(dy, src, 64), qdz = __shfl(dz, src, 64);
+			HitState hs = best;
+			hs.t = __shfl(best.t, src, 64);
+			hs.rank = __shfl(best.rank, src, 64);
+			const int leaf = __shfl(pend0, src, 64);
+			int res = 0;
+			if (todo || helper) {
+				if (STATS) leafFetches++;
+				res = wide_leaf_test<STATS>(sc.triWide + (size_t)((leaf >> 1) + (helper ? 1 : 0)) * 4, q, qdx, qdy, qdz, hs, boxTests, triTests);
+			}
+			// what the helper found, seen from the lane it helped
+			const int hres = __shfl(res, back, 64);
+			const float ht = __shfl(hs.t, back, 64), ha = __shfl(hs.alpha, back, 64), hb = __shfl(hs.beta, back, 64);
+			const int hrank = __shfl(hs.rank, back, 64);
+			bool aside = false;
+			if (todo) {
+				if (res == 1) {
+					best = hs;
+					found = true;
+				}
+				aside = res == 2;
+				if (helped) {
+					aside = aside || hres == 2;
+					if (hres == 1 && (ht < best.t || (ht == best.t && hrank < best.rank))) {
+						best.t = ht; best.alpha = ha; best.beta = hb; best.rank = hrank;
 						found = true;
-						if (ANYHIT) todo = false;
 					}
 				}
-				todo = todo && second;
-				if (k == 1 || __builtin_amdgcn_ballot_w64(todo) == 0ull) break;
-				T += 4;
+			}
+			// seconds without a helper
+			const bool alone = todo && second && !helped && !aside && !(ANYHIT && found);
+			if (__builtin_amdgcn_ballot_w64(alone) != 0ull) {
+				if (alone) {
+					if (STATS) leafFetches++;
+					const int res2 = wide_leaf_test<STATS>(sc.triWide + (size_t)((pend0 >> 1) + 1) * 4, r, dx, dy, dz, best, boxTests, triTests);
+					if (res2 == 1) found = true;
+					aside = res2 == 2;
+				}
+			}
+			if (aside) {
+				// the ray starts over in the binary-tree kernel
+				unsafeList[atomicAdd(unsafeCount, 1u)] = j;
+				busy = false;
+				cur = -1;
+				sp = 0;
+				pend0 = pend1 = -1;
 			}
 			if (busy && pend0 >= 0) {
 				pend0 = pend1;
