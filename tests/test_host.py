@@ -143,3 +143,17 @@ def test_texture_loaders_match_reference_goldens(native_libs, tmp_path):
         f.write(g["file_0"].tobytes()[:200])
     with pytest.raises(api.RtxError):
         api.load_texture(str(tmp_path / "broken.jpg"))
+
+
+def test_traversal_tree_pairs_and_collapse(tmp_path):
+    """raytracer_amd/csrc/rtx_wide.h on the host (tests/wide_tree_check.cpp, compiled here with g++): triangles that share
+    an edge and a box pair up (every quad of a displaced grid, given in the scene generator's order; nothing in a soup
+    of loose triangles, except an exact duplicate), mates are mutual and their common box stays within the limit; the
+    surface-area tree over the leaves, collapsed four wide and quantised, reaches every triangle record exactly once
+    and every triangle lies inside the decoded box of its leaf slot -- with one thread and with several."""
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "wide_tree_check.cpp")
+    exe = str(tmp_path / "wide_tree_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", src, "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
