@@ -726,7 +726,8 @@ void HostRayTracer::render(const std::string& outDir, int nDevices) {
 		}
 		for (const auto& e : errors)
 			if (!e.empty()) throw std::runtime_error("GPU path: " + e);
-		if (nDevices > 1) chk(hip.rtx_gather_tiles(scenes.data(), nDevices));
+		// RTX_GATHER_SELF=1 (tests on one GPU): the single share goes through the exchange as well, sent to itself
+		if (nDevices > 1 || std::getenv("RTX_GATHER_SELF")) chk(hip.rtx_gather_tiles(scenes.data(), nDevices));
 		std::vector<uint8_t> outputBuffer((size_t)width * height * 3);
 		if (deviceToneMap) chk(hip.rtx_tonemap_read(scenes[0], i, outputBuffer.data()));
 		else {

@@ -174,6 +174,14 @@ render_num %d
         assert got.shape == want.shape
         assert np.array_equal(got, want), "frame %d: %d bytes differ" % (i, (got != want).sum())
     assert want.std() > 10
+    # once more with the single tile share sent through the exchange step (rtx_gather_tiles: RCCL as the command line
+    # finds it, no torch in that process), the image wiped between pack and unpack: the same files, byte for byte
+    first = [open(os.path.join(d, "out_%03d.png" % i), "rb").read() for i in range(1, frames + 1)]
+    env = dict(os.environ, RTX_GATHER_SELF="1", RTX_GATHER_POISON="1")
+    res = subprocess.run([build.CLI_BIN, "config.txt"], cwd=d, capture_output=True, text=True, timeout=120, env=env)
+    assert res.returncode == 0, res.stdout + res.stderr
+    for i in range(1, frames + 1):
+        assert open(os.path.join(d, "out_%03d.png" % i), "rb").read() == first[i - 1], "frame %d differs after the exchange" % i
 
 
 def ball_mesh(rings, segs, radius, seed):
