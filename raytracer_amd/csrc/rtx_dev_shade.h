@@ -66,6 +66,7 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 	__shared__ unsigned s_tot[SHADE_THREADS / 64];
 	__shared__ unsigned s_base[SHADE_THREADS / 64];
 	__shared__ unsigned s_stat[3][SHADE_THREADS / 64];
+	unsigned deadAll = 0, shadedAll = 0, fetchAll = 0;  // thread 0: the block's counts over all its rounds
 	// The grid does not grow with the queue: a block walks over it in steps of the grid's width (every thread
 	// of a block makes the same number of rounds, so the barriers below are uniform).
 	for (long long base = (long long)blockIdx.x * SHADE_THREADS; base < n; base += (long long)gridDim.x * SHADE_THREADS) {
@@ -199,9 +200,11 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 			}
 			unsigned base = run ? atomicAdd(&cnt[0], run) : 0u;
 			for (int w = 0; w < SHADE_THREADS / 64; ++w) s_base[w] += base;
-			if (d) atomicAdd(&cnt[1], d);
-			if (sh) atomicAdd(&cnt[2], sh);
-			if (f) atomicAdd(&cnt[3], f);
+			// the counters share a cache line with the queue tail, and one line takes only ~90 atomics per
+			// microsecond: they are added once per block, after its last round
+			deadAll += d;
+			shadedAll += sh;
+			fetchAll += f;
 		}
 		__syncthreads();
 		const unsigned childBase = s_base[wave] + offset;
@@ -276,6 +279,11 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 			B[j] = make_int2((int)childBase, kind | flags | (int)(texel << 8));
 		}
 		__syncthreads();  // the LDS words are reused by the next round
+	}
+	if (threadIdx.x == 0) {
+		if (deadAll) atomicAdd(&cnt[1], deadAll);
+		if (shadedAll) atomicAdd(&cnt[2], shadedAll);
+		if (fetchAll) atomicAdd(&cnt[3], fetchAll);
 	}
 }
 
@@ -397,15 +405,30 @@ __global__ __launch_bounds__(256) void k_gather(DevScene sc, int n, float4* __re
 		A[j] = make_float4(ox, oy, oz, 0.0f);
 	}
 	if (LAST) {
+		// one set of atomics per block (the three counters lie in one cache line, which takes only ~90 atomics per
+		// microsecond: one per wave of a large grid would cost more than the gather itself)
+		__shared__ unsigned s_red[3][256 / 64];
 		for (int off = 32; off > 0; off >>= 1) {
 			dead += __shfl_down(dead, off, 64);
 			fetches += __shfl_down(fetches, off, 64);
 			untraced += __shfl_down(untraced, off, 64);
 		}
 		if ((threadIdx.x & 63) == 0) {
-			if (dead) atomicAdd(&cnt[1], dead);
-			if (fetches) atomicAdd(&cnt[3], fetches);
-			if (untraced) atomicAdd(&cnt[2], untraced);
+			s_red[0][threadIdx.x >> 6] = dead;
+			s_red[1][threadIdx.x >> 6] = fetches;
+			s_red[2][threadIdx.x >> 6] = untraced;
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			unsigned d = 0, f = 0, u = 0;
+			for (int w = 0; w < 256 / 64; ++w) {
+				d += s_red[0][w];
+				f += s_red[1][w];
+				u += s_red[2][w];
+			}
+			if (d) atomicAdd(&cnt[1], d);
+			if (f) atomicAdd(&cnt[3], f);
+			if (u) atomicAdd(&cnt[2], u);
 		}
 	}
 }

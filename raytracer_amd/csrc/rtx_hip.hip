@@ -805,7 +805,7 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 		if (rc) return rc;
 		for (int lv = s->maxDepth - 1; lv >= 0; --lv) {
 			const unsigned* nDev = lv ? s->dCounts.p + (size_t)lv * CNT_STRIDE : nullptr;
-			const dim3 grid((unsigned)std::min<size_t>((cap[lv] + 255) / 256, (size_t)s->numCUs * 16));
+			const dim3 grid((unsigned)std::min<size_t>((cap[lv] + 255) / 256, (size_t)s->numCUs * 8));  // one resident set of 256-thread blocks
 			if (lv == s->maxDepth - 1) {
 				// the children are the last level: its rays and any-hit answers lie in the buffers of its parity
 				const int last = s->maxDepth & 1;
