@@ -53,9 +53,12 @@ __device__ __forceinline__ void scatter_offset(const DevScene& sc, uint32_t key,
 }
 
 #ifndef RTX_SHADE_THREADS
-#define RTX_SHADE_THREADS 1024
+#define RTX_SHADE_THREADS 512
 #endif
-constexpr int SHADE_THREADS = RTX_SHADE_THREADS;  // 16 waves share one queue-tail atomic
+// The waves of a block share one queue-tail atomic per round.  96 VGPRs allow 20 waves per CU: two blocks of 512 threads
+// (one works while the other waits for its atomic and its barriers) beat one block of 1024; smaller blocks pay more in
+// atomics on the one tail than they gain.
+constexpr int SHADE_THREADS = RTX_SHADE_THREADS;
 
 __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level, const float4* __restrict__ rayO,
 											   const float4* __restrict__ rayD, const float4* __restrict__ hits, int n,
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 		}
 
 		// ---- queue slots for the children.  Inside a wave, per-kind ballots + popcounts give each lane its
-		// offset; the 16 wave totals of the block are scanned in LDS and the block claims its range of the
+		// offset; the wave totals of the block are scanned in LDS and the block claims its range of the
 		// next level's queue with a single atomic (one word takes only ~90 atomics per microsecond, so one
 		// atomic per wave would bound the kernel).
 		const unsigned lane = threadIdx.x & 63;
