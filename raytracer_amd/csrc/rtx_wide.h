@@ -51,8 +51,39 @@ inline void reset(float* mn, float* mx) {
 
 // Binned SAH split of prims[start,end) (16 bins per axis, one triangle per leaf).  Returns the split
 // position; both sides are non-empty.
+inline int g_bins = 16, g_sweepBelow = 0;
+inline int sweep_split(std::vector<Prim>& prims, int start, int end) {
+	const int n = end - start;
+	double bestCost = DBL_MAX;
+	int bestAxis = -1, bestAt = 0;
+	std::vector<double> rightArea((size_t)n);
+	for (int axis = 0; axis < 3; ++axis) {
+		std::sort(prims.begin() + start, prims.begin() + end, [axis](const Prim& a, const Prim& b) { return a.c[axis] < b.c[axis]; });
+		float mn[3], mx[3];
+		reset(mn, mx);
+		for (int i = n - 1; i > 0; --i) {
+			grow(mn, mx, prims[start + i].bmin, prims[start + i].bmax);
+			rightArea[i] = half_area(mn, mx);
+		}
+		reset(mn, mx);
+		for (int i = 1; i < n; ++i) {  // i on the left
+			grow(mn, mx, prims[start + i - 1].bmin, prims[start + i - 1].bmax);
+			const double cost = half_area(mn, mx) * i + rightArea[i] * (n - i);
+			if (cost < bestCost) {
+				bestCost = cost;
+				bestAxis = axis;
+				bestAt = i;
+			}
+		}
+	}
+	if (bestAxis != 2) std::sort(prims.begin() + start, prims.begin() + end, [bestAxis](const Prim& a, const Prim& b) { return a.c[bestAxis] < b.c[bestAxis]; });
+	return start + bestAt;
+}
+
 inline int sah_split(std::vector<Prim>& prims, int start, int end) {
-	constexpr int BINS = 16;
+	if (end - start <= g_sweepBelow) return sweep_split(prims, start, end);
+	constexpr int MAXBINS = 64;
+	const int BINS = g_bins;
 	float cmin[3], cmax[3];
 	reset(cmin, cmax);
 	for (int i = start; i < end; ++i)
@@ -66,16 +97,16 @@ inline int sah_split(std::vector<Prim>& prims, int start, int end) {
 		const float ext = cmax[axis] - cmin[axis];
 		if (!(ext > 0.0f)) continue;
 		const float scale = (float)BINS / ext;
-		int cnt[BINS] = {0};
-		float bmn[BINS][3], bmx[BINS][3];
+		int cnt[MAXBINS] = {0};
+		float bmn[MAXBINS][3], bmx[MAXBINS][3];
 		for (int b = 0; b < BINS; ++b) reset(bmn[b], bmx[b]);
 		for (int i = start; i < end; ++i) {
 			int b = std::min(BINS - 1, std::max(0, (int)((prims[i].c[axis] - cmin[axis]) * scale)));
 			cnt[b]++;
 			grow(bmn[b], bmx[b], prims[i].bmin, prims[i].bmax);
 		}
-		double rightArea[BINS];
-		int rightCnt[BINS];
+		double rightArea[MAXBINS];
+		int rightCnt[MAXBINS];
 		float rmn[3], rmx[3];
 		reset(rmn, rmx);
 		int rc = 0;
