@@ -193,6 +193,27 @@ int main() {
 		if (check_mates(verts, box, mate, 1.3)) return 1;
 		if (check_tree(box, mate, 1)) return 1;
 	}
+	// 4. no triangles at all, and trees whose interior nodes lack a child (as a caller's tree may): the collapse must end
+	{
+		std::vector<float> box;
+		std::vector<int> mate;
+		if (check_tree(box, mate, 1)) return 1;
+		using rtxwide::BinNode;
+		std::vector<BinNode> t(4);
+		for (BinNode& b : t) { for (int c = 0; c < 3; ++c) { b.bmin[c] = 0.0f; b.bmax[c] = 1.0f; } }
+		t[0].left = 1;               // root with a left child only
+		t[1].left = 2; t[1].right = 3;
+		t[2].tri = 0;
+		t[3].left = -1; t[3].right = -1;  // an interior node without children: not usable
+		std::vector<int> leafValue{0};
+		std::vector<float> wide;
+		int need = 0;
+		if (!rtxwide::collapse_wide(t, leafValue, wide, need, 1)) return fail("collapse_wide refused a lopsided tree");
+		if (wide.size() != 16) return fail("lopsided tree: expected one wide node", (long)wide.size() / 16);
+		int32_t code[4];
+		std::memcpy(code, &wide[10], 16);
+		if (code[0] != ~0 || code[1] || code[2] || code[3]) return fail("lopsided tree: expected the one leaf in slot 0", code[0], code[1]);
+	}
 	std::printf("ok\n");
 	return 0;
 }
