@@ -145,9 +145,11 @@ struct DevBuf {
 	size_t n = 0;
 	hipError_t alloc(size_t count) {
 		release();
-		n = count;
 		if (!count) return hipSuccess;
-		return hipMalloc((void**)&p, count * sizeof(T));
+		const hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+		if (e == hipSuccess) n = count;  // a failed allocation leaves an empty buffer, not a size without memory
+		else p = nullptr;
+		return e;
 	}
 	void release() {
 		if (p) (void)hipFree(p);
@@ -1736,7 +1738,8 @@ RTX_API int rtx_gather_tiles(rtx_scene* const* scenes, int n) {
 	std::vector<int> devices(n);
 	for (int r = 0; r < n; ++r) devices[r] = scenes[r]->device;
 	if (g_rccl.devices != devices) {
-		for (ncclComm_t c : g_rccl.comms) (void)g_rccl.commDestroy(c);
+		for (ncclComm_t c : g_rccl.comms)
+			if (c) (void)g_rccl.commDestroy(c);
 		g_rccl.comms.assign((size_t)n, nullptr);
 		g_rccl.devices.clear();
 		RCCLCHK(g_rccl.commInitAll(g_rccl.comms.data(), n, devices.data()));
