@@ -114,6 +114,10 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 				// one aligned 64-byte record serves every hit; the texture coordinates live apart
 				const float4* T = sc.triShade + (size_t)rank * 8;
 				float4 s0 = T[0], s1 = T[1], s2 = T[2], s3 = T[3];
+				// the texture coordinates lie in the same 128-byte line and are asked for with it: loaded where they are
+				// used, behind the material tests, they would cost a second round trip
+				const float4 u01 = T[4], u2 = T[5];
+				asm volatile("" : : "v"(u01.x), "v"(u01.y), "v"(u01.z), "v"(u01.w), "v"(u2.x), "v"(u2.y));
 				const float t = H.y, alpha = H.z, beta = H.w;
 				const int triFlags = __float_as_int(s3.w);
 				const int texId = __float_as_int(s3.z);
@@ -159,7 +163,6 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 						if (texId >= sc.nTex) atomicOr(sc.fault, FAULT_TEX_ID);
 						else if (texId >= 0) {
 							flags |= FLAG_TEX;
-							const float4 u01 = T[4], u2 = T[5];
 							float u = (alpha * u01.x + beta * u01.z) + g * u2.x;
 							float v = (alpha * u01.y + beta * u01.w) + g * u2.y;
 							texel = tex_fetch_rgb(sc, texId, u, v);

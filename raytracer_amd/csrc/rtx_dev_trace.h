@@ -339,9 +339,10 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(DevScene sc, const floa
 // +-inf, or NaN where the origin lies on a box plane.  Its folds over lanes 1 and 2 (y, z) skip a NaN, which
 // is the same as the unconstrained (-inf, +inf) a parent's wider slab gives, so the argument above still
 // holds.  A NaN in lane 0 (x) makes the reference accept the box whatever the other axes say, which a
-// parent need not do: a ray that meets that case at a leaf is set aside in a list for the binary-tree kernel
-// above, which evaluates every ancestor as the reference does; so are rays with a finite reciprocal beyond
-// 2^100 (whose products overflow) and rays that need more stack than this kernel has.  The quantised
+// parent need not do: a ray that meets that case at a leaf whose y and z slabs it misses (see wide_leaf_test) is
+// set aside in a list for the binary-tree kernel above, which evaluates every ancestor as the reference does; so
+// are rays with a finite reciprocal beyond 2^100 (whose products overflow) and rays that need more stack than
+// this kernel has.  The quantised
 // tests are homogeneous in 1/d; they use +-2^100 in place of +-inf and so prune a parallel ray by
 // "origin inside the slab, give or take the slack".
 //
@@ -354,16 +355,23 @@ constexpr float WIDE_MAX_INV = 1.2676506e30f;  // 2^100
 __device__ __forceinline__ float ubyte_f(unsigned v, int k) { return (float)((v >> (8 * k)) & 0xFFu); }
 
 // One triangle of a leaf of the wide tree: the reference's slab predicate on the triangle's own box (src/BVH.cpp:14-41;
-// lane 0 is never NaN where this returns 1 or 0, and fmaxf/fminf skip a NaN in lanes 1 and 2 as the reference's
-// folds do), then Triangle::hit.  T: the triangle's record in sc.triWide.  Returns 1 when the triangle was accepted
-// (best updated), 0 when not, 2 when the origin lies on an x plane of the box and the ray runs along it: the
-// reference accepts such a box whatever y and z say (NaN in lane 0), provided it gets there, which only its own
-// tree can tell.
+// fmaxf/fminf skip a NaN in lanes 1 and 2 as the reference's folds do), then Triangle::hit.  T: the triangle's record
+// in sc.triWide.  Returns 1 when the triangle was accepted (best updated), 0 when not, 2 when only the reference's
+// own tree can tell.
+// NaN in lane 0 (the origin lies on an x plane of the box and the ray runs along it): the reference accepts such a
+// box whatever y and z say, provided it gets there.  The folds here skip that NaN too, which leaves x unconstrained;
+// an ancestor's box contains this one, so x does not constrain it either (the origin's x lies within its range: its
+// lane 0 is +-inf on both sides, or NaN and then it accepts outright), and its y and z slabs are wider.  If y and z
+// pass here, every ancestor therefore passes, the reference gets to this box, and accepts it.  If they fail here the
+// reference still accepts the box once it gets there, which the ancestors' y and z decide: 2.
 template <bool STATS>
 __device__ __forceinline__ int wide_leaf_test(const float4* __restrict__ T, const RaySlab& r, float dx, float dy, float dz, HitState& best,
 											  unsigned& boxTests, unsigned& triTests) {
 	const float4 q0 = T[0], q1 = T[1], q2 = T[2];
 	const int rank = __float_as_int(T[3].y);
+	// all of the record is asked for at once: left to itself the compiler moves the loads of the plane normal and of the
+	// rank behind the box test, where they cost further memory round trips in every leaf phase (2 to 5 % of a launch)
+	asm volatile("" : : "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(rank));
 	const float v0x = q0.w, v0y = q1.x, v0z = q1.y, v1x = q1.z, v1y = q1.w, v1z = q2.x, v2x = q2.y, v2y = q2.z, v2z = q2.w;
 	const float lx = fminf(fminf(v0x, v1x), v2x), hx = fmaxf(fmaxf(v0x, v1x), v2x);
 	const float ly = fminf(fminf(v0y, v1y), v2y), hy = fmaxf(fmaxf(v0y, v1y), v2y);
@@ -374,7 +382,7 @@ __device__ __forceinline__ int wide_leaf_test(const float4* __restrict__ T, cons
 	const float tmin = fmaxf(fmaxf(r.nx ? t1x : t0x, r.ny ? t1y : t0y), r.nz ? t1z : t0z);
 	const float tmax = fminf(fminf(r.nx ? t0x : t1x, r.ny ? t0y : t1y), r.nz ? t0z : t1z);
 	if (STATS) boxTests++;
-	if (t0x != t0x || t1x != t1x) return 2;
+	if ((t0x != t0x || t1x != t1x) && tmax < tmin) return 2;
 	if (tmax < tmin) return 0;
 	if (STATS) triTests++;
 	return tri_test_vals(q0.x, q0.y, q0.z, v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z, rank, r.ox, r.oy, r.oz, dx, dy, dz, best) ? 1 : 0;
@@ -461,6 +469,8 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 					j = cnext + slot;
 					float4 O = rayO[j];
 					float4 D = rayD[j];
+					// the origin is asked for together with the direction, not behind the test of the direction's marker
+					asm volatile("" : : "v"(O.x), "v"(O.y), "v"(O.z));
 					if (D.w != 0.0f) {
 						// not to be traced: 1 = no ray at all (refraction under total internal reflection),
 						// 2 = a ray of the last level whose value is zero whether it hits or not
