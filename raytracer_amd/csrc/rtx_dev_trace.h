@@ -414,6 +414,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 	unsigned walkIters = 0, leafIters = 0, walkLanes = 0, leafLanes = 0;  // wave-level, kept by lane 0
 	unsigned walkIdle = 0, walkParked = 0, walkLeafWait = 0, leafIdle = 0, leafWalkers = 0, refills = 0, refillLanes = 0;  // likewise
 	unsigned overflows = 0;
+	unsigned alonePasses = 0, aloneLanes = 0, helpedLanes = 0;  // likewise
 	unsigned myVisits = 0, maxVisits = 0, over100 = 0, over300 = 0;
 	int cnext = 0, cend = 0;
 	bool more = true, firstChunk = true;
@@ -614,6 +615,11 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 			// seconds without a helper
 			const bool alone = todo && second && !helped && !aside && !(ANYHIT && found);
 			if (__builtin_amdgcn_ballot_w64(alone) != 0ull) {
+				if (STATS) {
+					alonePasses++;
+					aloneLanes += __popcll(__builtin_amdgcn_ballot_w64(alone));
+					helpedLanes += __popcll(__builtin_amdgcn_ballot_w64(helped));
+				}
 				if (alone) {
 					if (STATS) leafFetches++;
 					const int res2 = wide_leaf_test<STATS>(sc.triWide + (size_t)((pend0 >> 1) + 1) * 4, r, dx, dy, dz, best, boxTests, triTests);
@@ -782,6 +788,9 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 			atomicAdd(&stats[16], (unsigned long long)leafWalkers);
 			atomicAdd(&stats[17], (unsigned long long)refills);
 			atomicAdd(&stats[18], (unsigned long long)refillLanes);
+			atomicAdd(&stats[19], (unsigned long long)alonePasses);
+			atomicAdd(&stats[20], (unsigned long long)aloneLanes);
+			atomicAdd(&stats[21], (unsigned long long)helpedLanes);
 		}
 		for (int off = 32; off > 0; off >>= 1) overflows += __shfl_down(overflows, off, 64);
 		if (lane == 0) {

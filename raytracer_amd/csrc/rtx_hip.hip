@@ -928,6 +928,8 @@ int finish_stats(rtx_scene* s) {
 			std::fprintf(stderr, "[rtx] wide: per walk iteration %.1f lanes without a ray, %.1f holding two leaves, %.1f with leaves only; per leaf phase %.1f without a ray, %.1f walkers waiting; %llu refills of %.1f lanes\n",
 						 (double)s->hStats[12] / wi, (double)s->hStats[13] / wi, (double)s->hStats[14] / wi, (double)s->hStats[15] / li, (double)s->hStats[16] / li,
 						 s->hStats[17], (double)s->hStats[18] / (double)std::max(1ull, s->hStats[17]));
+			std::fprintf(stderr, "[rtx] wide: second triangles left without a helper: a second pass in %llu leaf phases, for %.1f lanes (%.1f helped)\n", s->hStats[19],
+						 (double)s->hStats[20] / (double)std::max(1ull, s->hStats[19]), (double)s->hStats[21] / (double)std::max(1ull, s->hStats[19]));
 			std::fprintf(stderr, "[rtx] wide: most node visits of one ray %llu, rays over 100: %llu, over 300: %llu\n", s->hStats[9], s->hStats[10], s->hStats[11]);
 		}
 		s->stats.wide_visits = s->hStats[4];
