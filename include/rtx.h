@@ -58,7 +58,7 @@ typedef struct rtx_stats {
 	uint64_t wide_visits;     /* 64-byte nodes of the 4-wide tree fetched (only filled by instrumented runs) */
 	uint64_t leaf_fetches;    /* 64-byte triangle records fetched by the wide traversal (instrumented runs)   */
 	uint64_t queue_retries;   /* pixel batches rendered again because a queue sized from earlier frames overflowed */
-	uint64_t rays_set_aside;  /* rays the wide traversal handed to the binary-tree kernel (rtx_render_frames only)  */
+	uint64_t rays_set_aside;  /* rays the wide traversal handed to the binary-tree kernel (rtx_render_frames, rtx_trace_rays) */
 	uint64_t rays_untraced;   /* last-level rays (counted in rays) whose value is zero hit or miss: not traversed   */
 	uint64_t rays_wave_traced;/* rays whose traversal proved long and was redone by a whole wave (rtx_render_frames only) */
 } rtx_stats;

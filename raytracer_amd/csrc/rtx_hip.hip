@@ -1583,6 +1583,7 @@ RTX_API int rtx_trace_rays(rtx_scene* s, int mode, uint32_t n, const float* orig
 			e = hipGetLastError();
 			if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
 			if (e == hipSuccess) e = hipMemcpy(s->hCounts + FAULT_WORD, s->dCounts.p + FAULT_WORD, sizeof(unsigned), hipMemcpyDeviceToHost);
+			if (e == hipSuccess) e = hipMemcpy(s->hCounts + UNSAFE_SLOT, s->dCounts.p + UNSAFE_SLOT, sizeof(unsigned), hipMemcpyDeviceToHost);
 			if (e == hipSuccess) rc = check_fault(s->hCounts[FAULT_WORD]);
 			if (e == hipSuccess) e = hipMemcpy(tri_ids, dIds.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
 			if (e == hipSuccess && t_alpha_beta) e = hipMemcpy(t_alpha_beta, dTab.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost);
@@ -1595,6 +1596,7 @@ RTX_API int rtx_trace_rays(rtx_scene* s, int mode, uint32_t n, const float* orig
 	if (rc) return rc;
 	s->stats.rays = n;
 	s->stats.rays_per_level[0] = n;
+	s->stats.rays_set_aside = s->hCounts[UNSAFE_SLOT];
 	return finish_stats(s);
 }
 

@@ -161,6 +161,49 @@ def test_secondary_like_rays_and_degenerate_rays(libs):
     assert 0.3 < (ids_o >= 0).mean() < 0.99
 
 
+def test_rays_along_an_x_plane_of_a_leaf_box(libs):
+    """dx = 0 with the origin's x on an x plane of a triangle's box: (bound - o) * (1/d) is 0 * inf = NaN in lane 0 of
+    the reference's slab test (src/BVH.cpp:14-41), which then accepts the box whatever y and z say, provided its
+    traversal gets there.  A ray that meets the box's y and z slabs stays in the wide traversal (every ancestor passes
+    as well); one that misses them by less than the traversal's slack is decided by the reference's own tree.  Both
+    kinds against the CPU restatement, and both kinds must occur."""
+    sc = scenes.mixed_scene(seed=6, width=16, height=16, detail=0.8)
+    O = load_into(binding.Oracle(), sc)
+    rt = gpu_scene(sc)
+    v = sc.tris["v"][:, :, :3]
+    lo, hi = v.min(1), v.max(1)
+    rng = np.random.default_rng(21)
+    n = 8000
+    pick = rng.integers(0, len(v), n)
+    side = rng.integers(0, 2, n)
+    px = np.where(side == 0, lo[pick, 0], hi[pick, 0])
+    py = lo[pick, 1] + rng.uniform(0, 1, n) * (hi[pick, 1] - lo[pick, 1])
+    pz = lo[pick, 2] + rng.uniform(0, 1, n) * (hi[pick, 2] - lo[pick, 2])
+    d = np.zeros((n, 3), np.float32)
+    d[:, 1] = rng.normal(0, 1, n)
+    d[:, 2] = rng.normal(0, 1, n)
+    beside = np.arange(n) >= n // 2
+    # the second half passes just outside the box in y, running along z (dy = 0) or nearly so
+    off = rng.uniform(1e-5, 2e-3, n) * np.where(rng.integers(0, 2, n) == 0, -1.0, 1.0)
+    py = np.where(beside, np.where(off > 0, hi[pick, 1] + off, lo[pick, 1] + off), py)
+    d[beside, 1] = np.where(rng.integers(0, 2, beside.sum()) == 0, 0.0, rng.normal(0, 1e-4, beside.sum()))
+    s = rng.uniform(0.5, 30.0, n)
+    o = np.stack([px, py - s * d[:, 1], pz - s * d[:, 2]], 1).astype(np.float32)
+    o[:, 0] = px   # exactly the plane
+    ids_o, tab_o = O.closest_hits(o, d)
+    for mode in (0, 1):
+        ids_g, tab_g = rt.trace_rays(o, d, mode)
+        assert np.array_equal(ids_o, ids_g), "mode %d: %d differ" % (mode, (ids_o != ids_g).sum())
+        hit = ids_o >= 0
+        assert_bits_equal(tab_o[hit], tab_g[hit], "t/alpha/beta mode %d" % mode)
+        if mode == 0:
+            aside = rt.stats()["rays_set_aside"]
+            # some rays needed the reference's tree (also rays through their own box: the plane is shared by the boxes
+            # of neighbouring triangles, which they pass by), others were settled by the wide traversal
+            assert 0 < aside < n, aside
+    assert 0.2 < (ids_o >= 0).mean() < 0.999
+
+
 def test_ties_resolve_in_reference_candidate_order(libs):
     """Stacks of exactly coincident triangles: every ray sees equal t from several candidates; the
     winner must be the first in the reference's depth-first candidate order."""
