@@ -396,7 +396,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 															   unsigned* __restrict__ unsafeCount, int refill, int chunk,
 															   int triBatch, const unsigned* __restrict__ nDev,
 															   int* __restrict__ longList, unsigned* __restrict__ longCount, int longVisits,
-															   int smallQueue, int tailVisits) {
+															   int smallQueue, int tailVisits, int tailLanes) {
 	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
 	// A queue of a few thousand rays cannot fill the chip with one ray per lane; its launch would last as long as
 	// its longest ray walked by a single lane.  All its rays go to k_trace_long, a wave each, at once.
@@ -523,6 +523,9 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 		// for later (two slots) and the walk goes on to what lies behind it.  That is speculative (the leaf
 		// may turn out to cut those nodes off) but keeps lanes out of the waiting room; the result does not
 		// depend on the order of the tests.
+		// A wave that has found the queue exhausted and is down to a few rays hands those to the wave-per-ray kernel: they
+		// are its longest, and one lane each would walk them one node after the other while the launch waits.
+		if (!more && 64 - nidle <= tailLanes) visitsLeft = 0;
 		const bool canWalk = busy && pend1 < 0 && (cur >= 0 || sp > 0);
 		const unsigned long long mWalk = __builtin_amdgcn_ballot_w64(canWalk);
 		const unsigned long long mLeaf = __builtin_amdgcn_ballot_w64(busy && pend0 >= 0);

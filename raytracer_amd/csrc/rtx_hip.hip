@@ -173,6 +173,7 @@ struct rtx_scene {
 	int longBlocksPerCU = 8;         // grid of k_trace_long (RTX_LONG_BLOCKS)
 	int smallQueueFactor = 16;       // queues of up to this many rays per wave of k_trace_long go there entirely (RTX_SMALL_QUEUE)
 	int longVisits = 64;             // nodes one lane walks for a ray before a whole wave takes the ray over (RTX_LONG_VISITS, 0 = never)
+	int tailLanes = 2;               // a wave down to this many rays after the queue's end hands them over at once (RTX_TAIL_LANES)
 	int tailVisits = 32;             // the same allowance for rays still in flight once a wave finds the queue exhausted (RTX_TAIL_VISITS)
 	long long mergeBlocks = 131072;  // frames of a multi-frame call share a batch up to this many 4x4-pixel blocks (RTX_MERGE_BLOCKS)
 	int traceRefill = TRACE_REFILL, traceChunk = TRACE_CHUNK, traceBlocksPerCU = 6, traceTriBatch = 28;  // tunables (RTX_TRACE_* env)
@@ -513,7 +514,7 @@ int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float
 	hipLaunchKernelGGL((k_trace_wide<STK, ANYHIT, ST>), grid, block, 0, s->stream, d, ro, rd, hits, n, stats, work,      \
 					   unsafeList, unsafeCount, s->traceRefill, s->traceChunk, s->traceTriBatch, nDev, longList, longCount, \
 					   s->longVisits, s->longVisits == INT_MAX ? -1 : s->numCUs * s->longBlocksPerCU * (TRACE_THREADS / 64) * s->smallQueueFactor, \
-					   s->longVisits == INT_MAX ? INT_MAX : s->tailVisits)
+					   s->longVisits == INT_MAX ? INT_MAX : s->tailVisits, s->longVisits == INT_MAX ? 0 : s->tailLanes)
 	if (need <= 16) {
 		if (st) RTX_LAUNCH(16, true); else RTX_LAUNCH(16, false);
 	}
@@ -982,6 +983,7 @@ RTX_API int rtx_scene_create(rtx_scene** out, int device) {
 	if (const char* e = std::getenv("RTX_SMALL_QUEUE")) s->smallQueueFactor = std::max(0, std::atoi(e));
 	if (const char* e = std::getenv("RTX_LONG_VISITS")) s->longVisits = std::atoi(e) > 0 ? std::atoi(e) : INT_MAX;
 	if (const char* e = std::getenv("RTX_TAIL_VISITS")) s->tailVisits = std::max(0, std::atoi(e));
+	if (const char* e = std::getenv("RTX_TAIL_LANES")) s->tailLanes = std::max(0, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_MERGE_BLOCKS")) s->mergeBlocks = std::max(1ll, std::atoll(e));
 	if (const char* e = std::getenv("RTX_TRACE_TRI_BATCH")) s->traceTriBatch = std::max(1, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_TRACE_BLOCKS_PER_CU")) s->traceBlocksPerCU = std::max(1, std::atoi(e));
