@@ -162,7 +162,8 @@ struct EventPair {
 	hipEvent_t a, b;
 	int kind;    // 0 trace, 1 shade/gather/accumulate, 2 whole call
 	int level;   // path level of a trace launch
-	bool ended;  // b has been recorded
+	bool ended;    // b has been recorded
+	bool sharedA;  // a is the b of the pair recorded just before: it is not this pair's to give back
 };
 
 }  // namespace
@@ -173,6 +174,8 @@ struct rtx_scene {
 	int longBlocksPerCU = 8;         // grid of k_trace_long (RTX_LONG_BLOCKS)
 	int smallQueueFactor = 16;       // queues of up to this many rays per wave of k_trace_long go there entirely (RTX_SMALL_QUEUE)
 	int longVisits = 64;             // nodes one lane walks for a ray before a whole wave takes the ray over (RTX_LONG_VISITS, 0 = never)
+	hipEvent_t lastEnd = nullptr;    // the event recorded by the last end_event, and whether nothing has been launched since
+	bool lastEndFresh = false;
 	int tailLanes = 2;               // a wave down to this many rays after the queue's end hands them over at once (RTX_TAIL_LANES)
 	int tailVisits = 32;             // the same allowance for rays still in flight once a wave finds the queue exhausted (RTX_TAIL_VISITS)
 	long long mergeBlocks = 131072;  // frames of a multi-frame call share a batch up to this many 4x4-pixel blocks (RTX_MERGE_BLOCKS)
@@ -272,6 +275,7 @@ int check_fault(unsigned bits) {
 // After every kernel launch: the launch error, and with RTX_SYNC_LAUNCHES=1 (debugging) the kernel's own
 // completion, reported under the kernel's name.
 int launched(rtx_scene* s, const char* kernel) {
+	s->lastEndFresh = false;
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess && s->syncLaunches) e = hipStreamSynchronize(s->stream);
 	if (e != hipSuccess) return fail(RTX_ERR_DEVICE, std::string(kernel) + ": " + hipGetErrorString(e));
@@ -409,11 +413,17 @@ int begin_event(rtx_scene* s, int kind, size_t& idx, int level = 0) {
 	idx = NO_EVENT;
 	if (!s->timeEvents) return RTX_OK;
 	EventPair e;
-	int rc = take_event(s, e.a);
+	// Where one timed group ends and the next begins with nothing launched in between, the end of the one is the beginning
+	// of the other: a record in the queue costs about 5 us between two kernels, which a frame of a small tile share or of a
+	// small scene pays twenty times.
+	e.sharedA = s->lastEndFresh;
+	int rc = RTX_OK;
+	if (e.sharedA) e.a = s->lastEnd;
+	else rc = take_event(s, e.a);
 	if (rc) return rc;
 	rc = take_event(s, e.b);
 	if (rc) {
-		s->eventPool.push_back(e.a);
+		if (!e.sharedA) s->eventPool.push_back(e.a);
 		return rc;
 	}
 	e.kind = kind;
@@ -421,23 +431,26 @@ int begin_event(rtx_scene* s, int kind, size_t& idx, int level = 0) {
 	e.ended = false;
 	s->events.push_back(e);
 	idx = s->events.size() - 1;
-	HIPCHK(hipEventRecord(e.a, s->stream));
+	if (!e.sharedA) HIPCHK(hipEventRecord(e.a, s->stream));
 	return RTX_OK;
 }
 int end_event(rtx_scene* s, size_t idx) {
 	if (idx == NO_EVENT) return RTX_OK;
 	HIPCHK(hipEventRecord(s->events[idx].b, s->stream));
 	s->events[idx].ended = true;
+	s->lastEnd = s->events[idx].b;
+	s->lastEndFresh = true;
 	return RTX_OK;
 }
 // Puts every recorded pair back into the pool without reading it: what an error path and the start of a call do,
 // so that a pair whose second event was never recorded cannot poison a later harvest.
 void drop_events(rtx_scene* s) {
 	for (auto& e : s->events) {
-		s->eventPool.push_back(e.a);
+		if (!e.sharedA) s->eventPool.push_back(e.a);
 		s->eventPool.push_back(e.b);
 	}
 	s->events.clear();
+	s->lastEndFresh = false;
 }
 // After a stream sync: fold event durations into the stats and recycle the events.  The list is emptied whether
 // or not every pair could be read.
