@@ -172,7 +172,8 @@ struct rtx_scene {
 	int device = 0;
 	int numCUs = 256;
 	int longBlocksPerCU = 8;         // grid of k_trace_long (RTX_LONG_BLOCKS)
-	int smallQueueFactor = 16;       // queues of up to this many rays per wave of k_trace_long go there entirely (RTX_SMALL_QUEUE)
+	int smallQueueFactor = 5;        // queues of up to this many rays per wave of k_trace_long go there entirely (RTX_SMALL_QUEUE): 40,960 rays, where a launch of
+	                                 // the one-ray-per-lane kernel (about 0.1 ms whatever the queue) starts to be the cheaper one
 	int longVisits = 64;             // nodes one lane walks for a ray before a whole wave takes the ray over (RTX_LONG_VISITS, 0 = never)
 	hipEvent_t lastEnd = nullptr;    // the event recorded by the last end_event, and whether nothing has been launched since
 	bool lastEndFresh = false;

@@ -542,7 +542,7 @@ def test_long_rays_taken_over_by_a_whole_wave(libs, monkeypatch, visits):
     rt.reset()
     rt.render(1, 2)
     st = rt.stats()
-    assert st["rays_wave_traced"] > st["rays"] // 4, st
+    assert st["rays_wave_traced"] > st["rays"] // 8, st   # the allowance, not the small-queue rule, sends them there
     want = np.zeros((sc.height, sc.width, 4), np.float32)
     for f in (1, 2):
         O.render_rows(f, want, nthreads=8)
