@@ -533,7 +533,10 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 			if (!more) break;
 			continue;
 		}
-		const bool leafPhase = __popcll(mLeaf) >= triBatch || mWalk == 0ull;
+		// The leaves are tested once triBatch of 64 lanes hold one -- of the lanes that have a ray: a wave that is running
+		// empty (the end of the queue, a short queue) would otherwise come to its leaves only when none of its lanes can
+		// walk any more, with the lanes that hold two leaves waiting all that time.
+		const bool leafPhase = __popcll(mLeaf) >= max(1, ((64 - nidle) * triBatch) >> 6) || mWalk == 0ull;
 		if (STATS) {
 			if (leafPhase) {
 				leafIters++;
