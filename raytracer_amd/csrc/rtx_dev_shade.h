@@ -55,9 +55,9 @@ __device__ __forceinline__ void scatter_offset(const DevScene& sc, uint32_t key,
 #ifndef RTX_SHADE_THREADS
 #define RTX_SHADE_THREADS 512
 #endif
-// The waves of a block share one queue-tail atomic per round.  96 VGPRs allow 20 waves per CU: two blocks of 512 threads
-// (one works while the other waits for its atomic and its barriers) beat one block of 1024; smaller blocks pay more in
-// atomics on the one tail than they gain.
+// The waves of a block share one queue-tail atomic per round.  72 VGPRs allow 28 waves per CU: three blocks of 512
+// threads (the others work while one waits for its atomic and its barriers) beat one block of 1024; smaller blocks pay
+// more in atomics on the one tail than they gain.  The grid is a multiple of three blocks per CU.
 constexpr int SHADE_THREADS = RTX_SHADE_THREADS;
 
 __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level, const float4* __restrict__ rayO,

@@ -177,6 +177,8 @@ struct rtx_scene {
 	int longVisits = 64;             // nodes one lane walks for a ray before a whole wave takes the ray over (RTX_LONG_VISITS, 0 = never)
 	hipEvent_t lastEnd = nullptr;    // the event recorded by the last end_event, and whether nothing has been launched since
 	bool lastEndFresh = false;
+	int shadeBlocksPerCU = 6;        // grid of k_shade (RTX_SHADE_BLOCKS_PER_CU): a multiple of the three blocks of 512 threads a CU holds at once, so that
+	                                 // the last set of blocks is a full one (four per CU: a third of the chip works through the last quarter)
 	int tailLanes = 2;               // a wave down to this many rays after the queue's end hands them over at once (RTX_TAIL_LANES)
 	int tailVisits = 32;             // the same allowance for rays still in flight once a wave finds the queue exhausted (RTX_TAIL_VISITS)
 	long long mergeBlocks = 131072;  // frames of a multi-frame call share a batch up to this many 4x4-pixel blocks (RTX_MERGE_BLOCKS)
@@ -811,7 +813,7 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 			unsigned* cnt = s->dCounts.p + (size_t)(lv + 1) * CNT_STRIDE;
 			rc = begin_event(s, 1, ev);
 			if (rc) return rc;
-			hipLaunchKernelGGL(k_shade, dim3((unsigned)std::min<size_t>((n + SHADE_THREADS - 1) / SHADE_THREADS, (size_t)s->numCUs * 4)), dim3(SHADE_THREADS), 0, s->stream, d, lv,
+			hipLaunchKernelGGL(k_shade, dim3((unsigned)std::min<size_t>((n + SHADE_THREADS - 1) / SHADE_THREADS, (size_t)s->numCUs * (size_t)s->shadeBlocksPerCU)), dim3(SHADE_THREADS), 0, s->stream, d, lv,
 							   rayO[cur], rayD[cur], hit[cur], (int)n, A[lv], B[lv], rayO[nxt], rayD[nxt], cnt, (unsigned)cap[lv + 1],
 							   nDev);
 			RTX_LAUNCHED("k_shade");
@@ -997,6 +999,7 @@ RTX_API int rtx_scene_create(rtx_scene** out, int device) {
 	if (const char* e = std::getenv("RTX_SMALL_QUEUE")) s->smallQueueFactor = std::max(0, std::atoi(e));
 	if (const char* e = std::getenv("RTX_LONG_VISITS")) s->longVisits = std::atoi(e) > 0 ? std::atoi(e) : INT_MAX;
 	if (const char* e = std::getenv("RTX_TAIL_VISITS")) s->tailVisits = std::max(0, std::atoi(e));
+	if (const char* e = std::getenv("RTX_SHADE_BLOCKS_PER_CU")) s->shadeBlocksPerCU = std::max(1, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_TAIL_LANES")) s->tailLanes = std::max(0, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_MERGE_BLOCKS")) s->mergeBlocks = std::max(1ll, std::atoll(e));
 	if (const char* e = std::getenv("RTX_TRACE_TRI_BATCH")) s->traceTriBatch = std::max(1, std::min(64, std::atoi(e)));
