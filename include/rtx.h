@@ -170,15 +170,17 @@ int rtx_primary_hits(rtx_scene* s, int mode, int32_t* tri_ids, float* t_alpha_be
 int rtx_trace_rays(rtx_scene* s, int mode, uint32_t n, const float* origins, const float* directions,
 				   int32_t* tri_ids, float* t_alpha_beta);
 
-/* rtx_trace_rays for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
- * that forbid hipMalloc).  It has no counterpart in the reference.  The four arrays are DEVICE memory of the
- * scene's GPU, laid out as for rtx_trace_rays (d_t_alpha_beta may be NULL); the call itself allocates nothing
- * on the device or through the runtime: ray records, hit records, the traversal's ray lists and its counters
- * live in a fixed array inside the library (14 MiB per GPU, held until the process ends), which limits one call
- * to RTX_NOALLOC_MAX_RAYS rays; more is RTX_ERR_ARG.  The scene needs its triangles and its tree, nothing else.
- * Work is enqueued on the scene's stream (the default stream if none was set) and the call blocks until it has
- * finished.  All scenes of one GPU share that GPU's array: calls that overlap on one GPU race.  No timing and
- * no test counters are taken (rtx_get_stats reports the ray count only). */
+/* rtx_trace_rays for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc, code
+ * that must not disturb a memory pool).  It has no counterpart in the reference.  The four arrays are DEVICE memory
+ * of the scene's GPU, laid out as for rtx_trace_rays (d_t_alpha_beta may be NULL); the call makes no hipMalloc,
+ * hipFree or other allocating call: ray records, hit records, the traversal's ray lists and its counters live in a
+ * fixed array inside the library (14 MiB per GPU, held until the process ends), which limits one call to
+ * RTX_NOALLOC_MAX_RAYS rays; more is RTX_ERR_ARG.  The one word it reads back (the kernels' consistency word)
+ * goes into pinned memory the scene obtained when it was created.  The scene needs its triangles and its tree,
+ * nothing else.  Work is enqueued on the scene's stream (the default stream if none was set) and the call BLOCKS
+ * until it has finished (hipStreamSynchronize), so it cannot be recorded into a HIP graph: a caller under stream
+ * capture has to end the capture first.  All scenes of one GPU share that GPU's array: calls that overlap on one
+ * GPU race.  No timing and no test counters are taken (rtx_get_stats reports the ray count only). */
 #define RTX_NOALLOC_MAX_RAYS (1u << 18)
 int rtx_trace_rays_noalloc(rtx_scene* s, int mode, uint32_t n, const float* d_origins, const float* d_directions,
 						   int32_t* d_tri_ids, float* d_t_alpha_beta);
@@ -189,16 +191,35 @@ int rtx_sample_radiance(rtx_scene* s, uint32_t frame, float* host_out);
 
 /* Several GPUs in one process: the exchange step after the row loop that rtx_scene_set_tiles split
  * (src/RayTracer.cpp:237; the reference's loop writes one shared accumulateImg, here every GPU holds its tile
- * share in an image of its own).  scenes[r], r = 0..n-1, live on n different GPUs, have the same image size and
- * hold the tile share (r, n) -- rtx_scene_set_tiles(scenes[r], r, n, -1).  The accumulator tiles of scenes
- * 1..n-1 are packed on their GPUs, sent to scenes[0]'s GPU with RCCL (one ncclSend/ncclRecv pair per peer inside
- * one group, i.e. one message per xGMI link, all at once) and written into scenes[0]'s accumulator, which then
- * is the whole image for rtx_tonemap_read / rtx_accum_read.  The other accumulators are left as they are.
- * Communicators are created on the first call (ncclCommInitAll over the scenes' devices) and kept for later
- * calls with the same devices.  librccl.so is opened at the first call; a process that never calls this does
- * not need it.  With n = 1 the single share is packed, sent to itself and unpacked (what a test on one GPU can
- * exercise).  Blocks until the image is complete.  One thread at a time. */
+ * share in an image of its own).  scenes[r], r = 0..n-1, have the same image size and hold the tile share
+ * (r, n) -- rtx_scene_set_tiles(scenes[r], r, n, -1).  The accumulator tiles of scenes 1..n-1 are packed on their
+ * GPUs, sent to scenes[0]'s GPU and written into scenes[0]'s accumulator, which then is the whole image for
+ * rtx_tonemap_read / rtx_accum_read.  The other accumulators are left as they are.
+ * Transport: the scenes live on n different GPUs -- RCCL, one ncclSend/ncclRecv pair per peer inside one group,
+ * i.e. one message per xGMI link, all at once; communicators are created on the first call (ncclCommInitAll over
+ * the scenes' devices) and kept for later calls with the same devices; librccl.so is opened at the first call, a
+ * process that never gets here does not need it -- or all on the same GPU (several worker threads sharing one
+ * device): then a message is a device-to-device copy.  Anything in between is RTX_ERR_ARG.  With n = 1 the single
+ * share is packed, sent to itself through RCCL and unpacked (what a test on one GPU can exercise of that path).
+ * Blocks until the image is complete.  One thread at a time. */
 int rtx_gather_tiles(rtx_scene* const* scenes, int n);
+
+/* The same exchange for dynamically balanced frames, where which scene renders which tile changes from frame to
+ * frame (worker threads pulling tile batches from a shared counter: rtx_scene_set_tiles(s, first, 1, count) +
+ * rtx_render_frames per batch).  Every scene keeps a log of the tiles it has rendered since the log was last
+ * cleared; the call moves exactly those tiles: a sender's logged tiles are packed and left ZERO, scenes[0] ADDS
+ * what it receives to its accumulator (x = x + contribution: bit for bit what rendering the tile into scenes[0]'s
+ * accumulator would have given, because a zeroed accumulator plus one frame's contribution is that contribution
+ * exactly), and all logs are cleared.  Called once per frame, it keeps scenes[0]'s accumulator equal to the
+ * single-GPU one; the accumulators of the other scenes are frame buffers that are empty between frames.  A tile
+ * logged by two scenes is RTX_ERR_ARG.  Transport and blocking as for rtx_gather_tiles. */
+int rtx_exchange_tiles(rtx_scene* const* scenes, int n);
+
+/* The log rtx_exchange_tiles works from: writes up to `capacity` tile numbers (ascending) and returns how many the
+ * log holds.  rtx_render_frames adds the tiles of the scene's share to it; rtx_exchange_tiles, rtx_accum_reset and
+ * rtx_scene_tile_log_clear empty it. */
+int rtx_scene_tile_log(rtx_scene* s, int* tiles, int capacity);
+int rtx_scene_tile_log_clear(rtx_scene* s);
 
 /* When enabled, traversal kernels count box and triangle tests (slower). */
 int rtx_scene_set_instrumented(rtx_scene* s, int enabled);

@@ -118,6 +118,7 @@ class Oracle(_Base):
         self.draw = L._fn("draw", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
         self._sample_radiance = L._fn("sample_radiance", None, _vp, _i, _i, _i, _i, _i, _fp)
         self._render_rows = L._fn("render_rows", C.c_double, _vp, _i, _i, _i, _fp, _vp, _i)
+        self._render_pixels = L._fn("render_pixels", C.c_double, _vp, _i, _i, _ip, _fp, _i)
         self._worst_ray = L._fn("worst_ray", None, _vp, _fp)
         self._ray_count = L._fn("ray_count", C.c_uint64, _vp)
         self._tir_count = L._fn("tir_count", C.c_uint64, _vp)
@@ -268,6 +269,12 @@ class Oracle(_Base):
         assert accum.dtype == np.float32 and accum.flags.c_contiguous
         p8 = out8.ctypes.data if out8 is not None else None
         return self._render_rows(self.h, frame, row0, row1, _fptr(accum), p8, nthreads)
+
+    def render_pixels(self, frame, xy, accum, nthreads=1):
+        """The loop body for the listed pixels only: xy (n, 2) int32 as (col, row); accumulates into accum."""
+        xy = np.ascontiguousarray(xy, np.int32).reshape(-1, 2)
+        assert accum.dtype == np.float32 and accum.flags.c_contiguous
+        return self._render_pixels(self.h, frame, len(xy), _iptr(xy), _fptr(accum), nthreads)
 
     def worst_ray(self):
         out = np.zeros(8, np.float32)

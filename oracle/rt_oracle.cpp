@@ -1024,6 +1024,49 @@ ORC_API double orc_render_rows(void* h, int frame, int row0, int row1, float* ac
 	return std::chrono::duration<double>(t1 - t0).count();
 }
 
+
+// The same loop body for a list of pixels instead of whole rows: pixel k is (xy[2k], xy[2k+1]); a pixel listed twice is
+// accumulated twice.  Lets a test look at blocks scattered over a large image at the price of a few rows.
+ORC_API double orc_render_pixels(void* h, int frame, int n, const int* xy, float* accum, int nthreads) {
+	Scene& s = *(Scene*)h;
+	std::atomic<int> next(0);
+	std::atomic<uint64_t> rays(0), tirs(0);
+	auto worker = [&] {
+		Ctx cx;
+		cx.s = &s;
+		cx.rng.mode = RNG_COUNTER;
+		for (;;) {
+			const int k0 = next.fetch_add(16);
+			if (k0 >= n) break;
+			for (int k = k0; k < std::min(n, k0 + 16); ++k) {
+				const int col = xy[2 * k], row = xy[2 * k + 1];
+				if (col < 0 || col >= s.width || row < 0 || row >= s.height) continue;
+				V4 temp = mk(0, 0, 0, 0);
+				for (int i = 0; i < 4; ++i) {
+					uint32_t sample = ((uint32_t)row * (uint32_t)s.width + (uint32_t)col) * 4u + (uint32_t)i;
+					temp = temp + color(cx, 0, get_ray(s, col, row, i), rt_sample_key(s.seed, (uint32_t)frame, sample));
+				}
+				float* px = accum + ((size_t)row * s.width + col) * 4;
+				V4 add = temp * 0.25f;
+				px[0] += add.x;
+				px[1] += add.y;
+				px[2] += add.z;
+				px[3] += add.w;
+			}
+		}
+		rays += cx.rays;
+		tirs += cx.tir;
+	};
+	auto t0 = std::chrono::steady_clock::now();
+	if (nthreads < 1) nthreads = 1;
+	std::vector<std::thread> pool;
+	for (int i = 0; i < nthreads; ++i) pool.emplace_back(worker);
+	for (auto& th : pool) th.join();
+	auto t1 = std::chrono::steady_clock::now();
+	s.rayCount += rays.load();
+	s.tirCount += tirs.load();
+	return std::chrono::duration<double>(t1 - t0).count();
+}
 // Diagnostics: candidates, depth, origin, direction of the ray with the longest BVH::hit list in
 // the last orc_render_rows call.
 ORC_API void orc_worst_ray(void* h, float* out8) { std::memcpy(out8, ((Scene*)h)->worst, 32); }

@@ -68,6 +68,9 @@ HIP_SYMBOLS = {
     "rtx_trace_rays_noalloc": (_i, [_vp, _i, _u32, _vp, _vp, _vp, _vp]),
     "rtx_sample_radiance": (_i, [_vp, _u32, _fp]),
     "rtx_gather_tiles": (_i, [C.POINTER(_vp), _i]),
+    "rtx_exchange_tiles": (_i, [C.POINTER(_vp), _i]),
+    "rtx_scene_tile_log": (_i, [_vp, _ip, _i]),
+    "rtx_scene_tile_log_clear": (_i, [_vp]),
     "rtx_scene_set_instrumented": (_i, [_vp, _i]),
     "rtx_get_stats": (_i, [_vp, C.POINTER(Stats)]),
 }
@@ -210,6 +213,13 @@ def gather_tiles(tracers):
     _chk(hip_lib().rtx_gather_tiles(arr, len(tracers)))
 
 
+def exchange_tiles(tracers):
+    """rtx_exchange_tiles: the tiles every tracer has rendered since the last exchange are added to tracers[0]'s
+    accumulator and zeroed where they came from (dynamically balanced frames)."""
+    arr = (_vp * len(tracers))(*[t.h for t in tracers])
+    _chk(hip_lib().rtx_exchange_tiles(arr, len(tracers)))
+
+
 # ---- the device-side scene -----------------------------------------------------------------------
 
 class RayTracer:
@@ -285,6 +295,16 @@ class RayTracer:
 
     def set_tiles(self, first=0, stride=1, count=-1):
         _chk(self.lib.rtx_scene_set_tiles(self.h, first, stride, count))
+
+    def tile_log(self):
+        """Tile numbers rendered into the accumulator since the log was last cleared."""
+        n = _chk(self.lib.rtx_scene_tile_log(self.h, None, 0))
+        out = np.zeros(max(n, 1), np.int32)
+        _chk(self.lib.rtx_scene_tile_log(self.h, out.ctypes.data_as(_ip), n))
+        return out[:n]
+
+    def clear_tile_log(self):
+        _chk(self.lib.rtx_scene_tile_log_clear(self.h))
 
     def set_arena_bytes(self, nbytes):
         _chk(self.lib.rtx_scene_set_arena_bytes(self.h, nbytes))

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -332,6 +333,7 @@ struct HipApi {
 	RTX_FN(rtx_tonemap_read)
 	RTX_FN(rtx_get_stats)
 	RTX_FN(rtx_gather_tiles)
+	RTX_FN(rtx_exchange_tiles)
 #undef RTX_FN
 };
 
@@ -363,6 +365,7 @@ void bind_hip(HipApi& api) {
 	RTX_FN(rtx_tonemap_read)
 	RTX_FN(rtx_get_stats)
 	RTX_FN(rtx_gather_tiles)
+	RTX_FN(rtx_exchange_tiles)
 #undef RTX_FN
 }
 
@@ -608,7 +611,33 @@ void HostRayTracer::render(const std::string& outDir, int nDevices) {
 	};
 	const int avail = chk(hip.rtx_device_count());
 	if (nDevices < 1) nDevices = 1;
-	if (nDevices > avail) throw std::runtime_error("GPU path: " + std::to_string(nDevices) + " devices requested, " + std::to_string(avail) + " present");
+	// Which GPU each of the nDevices workers drives: 0, 1, 2, ... unless RTX_DEVICE_MAP lists them ("0,0" = two
+	// workers sharing GPU 0, whose tiles then meet by a copy inside that GPU instead of over RCCL).
+	std::vector<int> deviceOf(nDevices);
+	for (int d = 0; d < nDevices; ++d) deviceOf[d] = d;
+	if (const char* e = std::getenv("RTX_DEVICE_MAP")) {
+		std::vector<int> ids;
+		for (const char* p = e; *p;) {
+			char* end = nullptr;
+			const long v = std::strtol(p, &end, 10);
+			if (end == p) break;
+			ids.push_back((int)v);
+			p = end;
+			while (*p == ',' || *p == ' ') ++p;
+		}
+		if ((int)ids.size() != nDevices) throw std::runtime_error("GPU path: RTX_DEVICE_MAP lists " + std::to_string(ids.size()) + " devices for " + std::to_string(nDevices) + " workers");
+		deviceOf = ids;
+	}
+	for (int d : deviceOf)
+		if (d < 0 || d >= avail) throw std::runtime_error("GPU path: device " + std::to_string(d) + " requested, " + std::to_string(avail) + " present");
+	// How the tiles of a frame are shared out among several workers.  static: worker d renders the tiles d, d + n, ...
+	// of every frame.  dynamic (the default): the first part of the tiles is interleaved the same way, the rest
+	// (RTX_DYNAMIC_PERCENT of them, default 25) is handed out in small batches from one atomic counter to whichever
+	// worker comes first, so that a GPU that is slower on its share -- or busy with something else -- takes fewer.
+	bool dynamicBalance = nDevices > 1;
+	if (const char* e = std::getenv("RTX_BALANCE")) dynamicBalance = nDevices > 1 && std::string(e) != "static";
+	int dynamicPercent = 25;
+	if (const char* e = std::getenv("RTX_DYNAMIC_PERCENT")) dynamicPercent = std::max(1, std::min(100, std::atoi(e)));
 
 	std::vector<NodeRec> nodes;
 	unsigned hw = std::thread::hardware_concurrency();
@@ -640,7 +669,7 @@ void HostRayTracer::render(const std::string& outDir, int nDevices) {
 
 	const float bg[3] = {backgroundColor.x, backgroundColor.y, backgroundColor.z};
 	for (int d = 0; d < nDevices; ++d) {
-		chk(hip.rtx_scene_create(&devs[d].scene, d));
+		chk(hip.rtx_scene_create(&devs[d].scene, deviceOf[d]));
 		rtx_scene* s = devs[d].scene;
 		chk(hip.rtx_scene_set_params(s, width, height, maxRecursionDepth, diffuseRayNum, specularRayNum, bg, 0x5EEDull));
 		chk(hip.rtx_scene_set_camera(s, &cam[0].x, &cam[1].x, &cam[2].x, &cam[3].x));
@@ -702,13 +731,19 @@ void HostRayTracer::render(const std::string& outDir, int nDevices) {
 		}
 	} joinWriter{mu, cv, done, writer};
 
-	// Every device renders its tile share of frame i on a thread of its own; the shares then travel to device 0
-	// over RCCL (one message per peer, each over its own xGMI link, rtx_gather_tiles) and device 0 alone hands
-	// the image back: 8-bit from its tone map, or the accumulator if the table could not be built.
+	// Every worker renders its tiles of frame i on a thread of its own; the tiles then travel to worker 0's GPU (one
+	// message per peer, each over its own xGMI link, all at once) and worker 0 alone hands the image back: 8-bit from
+	// its tone map, or the accumulator if the table could not be built.
+	//   static   worker d keeps the accumulators of its share over the frames; rtx_gather_tiles copies them over.
+	//   dynamic  a worker's image collects one frame's contributions, whichever tiles it happened to render;
+	//            rtx_exchange_tiles adds them to worker 0's accumulator and leaves the worker's image empty again.
 	std::vector<float> accumulateImg;
 	if (!deviceToneMap) accumulateImg.assign((size_t)width * height * 4, 0.0f);
 	std::vector<rtx_scene*> scenes(nDevices);
 	for (int d = 0; d < nDevices; ++d) scenes[d] = devs[d].scene;
+	const int numTiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+	const int headTiles = dynamicBalance ? (int)((long long)numTiles * (100 - dynamicPercent) / 100) / nDevices * nDevices : numTiles;
+	const int batchTiles = std::max(1, (numTiles - headTiles) / (nDevices * 4));
 	for (int i = 1; i <= renderNum; ++i) {
 		auto time1 = std::chrono::system_clock::now();
 		std::vector<std::string> errors(nDevices);
@@ -716,18 +751,36 @@ void HostRayTracer::render(const std::string& outDir, int nDevices) {
 			if (hip.rtx_render_frames(scenes[0], (uint32_t)i, 1) < 0) errors[0] = hip.rtx_last_error();
 		}
 		else {
+			std::atomic<int> nextTile(headTiles);  // the seam of tbb::parallel_for's own work stealing (src/RayTracer.cpp:237)
 			std::vector<std::thread> workers;
 			for (int d = 0; d < nDevices; ++d)
 				workers.emplace_back([&, d] {
 					// rtx_last_error is per thread: fetch it on the thread that made the call
-					if (hip.rtx_render_frames(scenes[d], (uint32_t)i, 1) < 0) errors[d] = hip.rtx_last_error();
+					auto run = [&](int first, int stride, int count) {
+						if (hip.rtx_scene_set_tiles(scenes[d], first, stride, count) < 0 || hip.rtx_render_frames(scenes[d], (uint32_t)i, 1) < 0) {
+							errors[d] = hip.rtx_last_error();
+							return false;
+						}
+						return true;
+					};
+					if (!dynamicBalance) {
+						run(d, nDevices, -1);
+						return;
+					}
+					if (headTiles > 0 && !run(d, nDevices, headTiles / nDevices)) return;
+					for (;;) {
+						const int first = nextTile.fetch_add(batchTiles);
+						if (first >= numTiles) break;
+						if (!run(first, 1, std::min(batchTiles, numTiles - first))) return;
+					}
 				});
 			for (auto& w : workers) w.join();
 		}
 		for (const auto& e : errors)
 			if (!e.empty()) throw std::runtime_error("GPU path: " + e);
 		// RTX_GATHER_SELF=1 (tests on one GPU): the single share goes through the exchange as well, sent to itself
-		if (nDevices > 1 || std::getenv("RTX_GATHER_SELF")) chk(hip.rtx_gather_tiles(scenes.data(), nDevices));
+		if (dynamicBalance) chk(hip.rtx_exchange_tiles(scenes.data(), nDevices));
+		else if (nDevices > 1 || std::getenv("RTX_GATHER_SELF")) chk(hip.rtx_gather_tiles(scenes.data(), nDevices));
 		std::vector<uint8_t> outputBuffer((size_t)width * height * 3);
 		if (deviceToneMap) chk(hip.rtx_tonemap_read(scenes[0], i, outputBuffer.data()));
 		else {

@@ -527,27 +527,51 @@ __global__ __launch_bounds__(256) void k_tonemap(const float4* __restrict__ accu
 	}
 }
 
-// Exchange of tile accumulators between GPUs.  A share is the tiles first, first + stride, ...; slot k of the packed
-// array holds tile first + k * stride as TILE x TILE float4 in row-major order (pixels beyond the image: zero).
-// k_pack_tiles copies a share out of an image, k_unpack_tiles copies one into an image.  One thread per pixel slot.
-__global__ __launch_bounds__(256) void k_pack_tiles(const float4* __restrict__ accum, int width, int height, int tilesX, int first,
-													int stride, int slots, float4* __restrict__ packed) {
+// Exchange of tile accumulators between GPUs.  A share is a list of tile numbers (row-major 64 x 64 tiles); slot k of
+// the packed array holds tile ids[k] as TILE x TILE float4 in row-major order (pixels beyond the image: zero).
+// k_pack_tiles copies a share out of an image -- and, with `clear`, leaves zeros behind, so that an image that
+// collects one frame's contributions is empty again for the next frame; k_unpack_tiles copies one into an image, or
+// with `add` adds it (x = x + packed: what k_accumulate would have done had the frame been rendered into that
+// image directly, bit for bit).  One thread per pixel slot.
+__global__ __launch_bounds__(256) void k_pack_tiles(float4* __restrict__ accum, int width, int height, int tilesX, const int* __restrict__ ids,
+													int slots, int numTiles, float4* __restrict__ packed, int clear) {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	if (i >= slots * TILE * TILE) return;
 	const int slot = i / (TILE * TILE), p = i - slot * (TILE * TILE);
-	const int tile = first + slot * stride;
-	const int x = (tile % tilesX) * TILE + (p % TILE), y = (tile / tilesX) * TILE + p / TILE;
-	packed[i] = (x < width && y < height) ? accum[(size_t)y * width + x] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	const int tile = ids[slot];
+	float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	if ((unsigned)tile < (unsigned)numTiles) {
+		const int x = (tile % tilesX) * TILE + (p % TILE), y = (tile / tilesX) * TILE + p / TILE;
+		if (x < width && y < height) {
+			float4* px = accum + (size_t)y * width + x;
+			v = *px;
+			if (clear) *px = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		}
+	}
+	packed[i] = v;
 }
 
-__global__ __launch_bounds__(256) void k_unpack_tiles(float4* __restrict__ accum, int width, int height, int tilesX, int first,
-													  int stride, int slots, const float4* __restrict__ packed) {
+__global__ __launch_bounds__(256) void k_unpack_tiles(float4* __restrict__ accum, int width, int height, int tilesX, const int* __restrict__ ids,
+													  int slots, int numTiles, const float4* __restrict__ packed, int add) {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	if (i >= slots * TILE * TILE) return;
 	const int slot = i / (TILE * TILE), p = i - slot * (TILE * TILE);
-	const int tile = first + slot * stride;
+	const int tile = ids[slot];
+	if ((unsigned)tile >= (unsigned)numTiles) return;
 	const int x = (tile % tilesX) * TILE + (p % TILE), y = (tile / tilesX) * TILE + p / TILE;
-	if (x < width && y < height) accum[(size_t)y * width + x] = packed[i];
+	if (x >= width || y >= height) return;
+	float4* px = accum + (size_t)y * width + x;
+	const float4 v = packed[i];
+	if (add) {
+		float4 a = *px;
+		a.x = a.x + v.x;
+		a.y = a.y + v.y;
+		a.z = a.z + v.z;
+		a.w = a.w + v.w;
+		*px = a;
+	}
+	else
+		*px = v;
 }
 
 // Per-sample radiance export (rtx_sample_radiance): out[(y*W+x)*4+sub] = A[j].

@@ -233,8 +233,14 @@ struct rtx_scene {
 	DevBuf<float4> dAccumOwn;
 	float4* dAccum = nullptr;  // own or external
 	bool texDirty = true;
-	DevBuf<float4> dTilePack;   // rtx_gather_tiles: this scene's share, packed (the share that is sent)
-	DevBuf<float4> dTileRecv;   // rtx_gather_tiles, scene 0: the shares of the others as they arrive
+	DevBuf<float4> dTilePack;   // tile exchange: this scene's share, packed (the share that is sent)
+	DevBuf<float4> dTileRecv;   // tile exchange, scene 0: the shares of the others as they arrive
+	DevBuf<int> dTileIds;       // tile exchange: the tile numbers of this scene's share (what k_pack_tiles walks over)
+	DevBuf<int> dTileIdsRecv;   // tile exchange, scene 0: the tile numbers of every sender's share, in the order of the receive buffer
+	int* hTileIds = nullptr;    // pinned staging of the two id arrays (own share first, then what scene 0 receives)
+	size_t hTileIdsCap = 0;
+	hipEvent_t exchEvent = nullptr;  // "this scene's share is packed", for a receiver on another stream of the same GPU
+	std::vector<uint8_t> tileLog;    // per tile: rendered into the accumulator since the log was last cleared (rtx_exchange_tiles)
 	DevBuf<uint8_t> arena;
 	DevBuf<unsigned> dCounts;           // 8 per level
 	DevBuf<unsigned long long> dStats;  // node tests, tri tests
@@ -243,6 +249,7 @@ struct rtx_scene {
 	std::vector<EventPair> events;       // pairs recorded since the last harvest
 	std::vector<hipEvent_t> eventPool;   // events waiting to be used again (created on demand, destroyed with the scene)
 	unsigned char* noallocScratch = nullptr;  // this device's copy of the file-scope scratch array
+	unsigned* hNoallocFault = nullptr;        // pinned word (obtained once, at rtx_scene_create) the fault word of rtx_trace_rays_noalloc is copied into
 	bool timeEvents = true;              // false: kernels are launched without timing events (the entry point that allocates nothing)
 	rtx_stats stats;
 
@@ -252,6 +259,10 @@ struct rtx_scene {
 		dTables.release(); dAccumOwn.release(); dTilePack.release(); dTileRecv.release(); arena.release(); dCounts.release(); dStats.release();
 		if (hCounts) (void)hipHostFree(hCounts);
 		if (hStats) (void)hipHostFree(hStats);
+		if (hNoallocFault) (void)hipHostFree(hNoallocFault);
+		if (hTileIds) (void)hipHostFree(hTileIds);
+		if (exchEvent) (void)hipEventDestroy(exchEvent);
+		dTileIds.release(); dTileIdsRecv.release();
 		for (auto& e : events) {
 			(void)hipEventDestroy(e.a);
 			(void)hipEventDestroy(e.b);
@@ -770,6 +781,9 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 		float4* hit[2] = {(float4*)(bump.base + bump.hi + 2 * setBytes), (float4*)(bump.base + bump.hi + 5 * setBytes)};
 
 		HIPCHK(hipMemsetAsync(s->dCounts.p, 0, COUNT_WORDS * sizeof(unsigned), s->stream));
+		// a batch's first timed group starts at an event of its own: the end of the previous batch lies before that
+		// batch's counter copy, the host's planning and a possible reallocation of the arena, none of which is shading
+		s->lastEndFresh = false;
 		size_t ev;
 		rc = begin_event(s, 1, ev);
 		if (rc) return rc;
@@ -855,11 +869,13 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 		if (rc) return rc;
 		HIPCHK(hipMemcpyAsync(s->hCounts, s->dCounts.p, COUNT_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
 		HIPCHK(hipStreamSynchronize(s->stream));
-		rc = harvest_events(s);
-		if (rc) return rc;
 
 		bool overflow = false;
 		for (int lv = 0; lv <= s->maxDepth; ++lv) overflow = overflow || s->hCounts[(size_t)(lv + 1) * CNT_STRIDE + 4] != 0;
+		// the kernel times of an attempt that is rendered again belong to no frame
+		if (overflow) drop_events(s);
+		else rc = harvest_events(s);
+		if (rc) return rc;
 		// what the levels asked for, whether or not it fitted (the cursor runs on past the capacity)
 		double asked[MAX_DEPTH + 2];
 		asked[0] = 1.0;
@@ -876,9 +892,16 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 			const double growth = std::max(1.0, asked[first] / std::max(asked[first - 1], 1.0 / 64.0));
 			for (int lv = 1; lv <= s->maxDepth; ++lv) {
 				double want = asked[lv] * 1.3 + 1.0 / 64.0;
-				if (lv <= first) s->popRatio[lv] = std::max(s->popRatio[lv], asked[lv]);
-				else want = std::max(want, s->capRatio[lv - 1] * growth);
-				s->capRatio[lv] = std::min(worst_ratio(s, lv), std::max(s->capRatio[lv], want));
+				if (lv <= first) {
+					// a true count: it replaces the guess the level started with, so that a later plan adds up what the
+					// levels hold and not what was guessed for them
+					s->popRatio[lv] = std::max(s->popRatio[lv], asked[lv]);
+					s->capRatio[lv] = std::min(worst_ratio(s, lv), lv > s->capKnown ? std::max(want, s->popRatio[lv] * 1.3 + 1.0 / 64.0) : std::max(s->capRatio[lv], want));
+				}
+				else {
+					want = std::max(want, s->capRatio[lv - 1] * growth);
+					s->capRatio[lv] = std::min(worst_ratio(s, lv), std::max(s->capRatio[lv], want));
+				}
 			}
 			s->capKnown = std::max(s->capKnown, first);
 			s->stats.chunks--;
@@ -985,7 +1008,14 @@ RTX_API int rtx_scene_create(rtx_scene** out, int device) {
 	if (!s) return fail(RTX_ERR_MEMORY, "out of host memory");
 	s->device = device;
 	{
-		const int rc = scratch_for_device(device, &s->noallocScratch);
+		int rc = scratch_for_device(device, &s->noallocScratch);
+		// the one host word rtx_trace_rays_noalloc reads back: pinned, so that its copy is a plain DMA into memory that
+		// exists already (a copy into pageable memory is staged by the runtime, through memory the runtime obtains)
+		if (rc == RTX_OK && hipHostMalloc((void**)&s->hNoallocFault, 64, hipHostMallocDefault) != hipSuccess) {
+			(void)hipGetLastError();
+			s->hNoallocFault = nullptr;
+			rc = fail(RTX_ERR_MEMORY, "cannot allocate the scene's pinned status word");
+		}
 		if (rc) {
 			delete s;
 			return rc;
@@ -1434,6 +1464,7 @@ RTX_API int rtx_accum_reset(rtx_scene* s) {
 	if (rc) return rc;
 	HIPCHK(hipMemsetAsync(s->dAccum, 0, (size_t)s->width * s->height * sizeof(float4), s->stream));
 	HIPCHK(hipStreamSynchronize(s->stream));
+	std::fill(s->tileLog.begin(), s->tileLog.end(), 0);
 	return RTX_OK;
 }
 
@@ -1470,6 +1501,12 @@ RTX_API int rtx_render_frames(rtx_scene* s, uint32_t first_frame, uint32_t n_fra
 	if (e != hipSuccess) return fail(RTX_ERR_DEVICE, hipGetErrorString(e));
 	rc = harvest_events(s);
 	if (rc) return rc;
+	// the tiles of the share now hold what this call rendered: rtx_exchange_tiles moves exactly those
+	{
+		const int total = num_tiles(s);
+		if ((int)s->tileLog.size() != total) s->tileLog.assign((size_t)total, 0);
+		for (int k = 0, n = tile_slots(s); k < n; ++k) s->tileLog[(size_t)(s->tileFirst + k * s->tileStride)] = 1;
+	}
 	return finish_stats(s);
 }
 
@@ -1627,7 +1664,7 @@ RTX_API int rtx_trace_rays_noalloc(rtx_scene* s, int mode, uint32_t n, const flo
 		return fail(RTX_ERR_ARG, "rtx_trace_rays_noalloc takes at most " + std::to_string(RTX_NOALLOC_MAX_RAYS) + " rays per call (" +
 									 std::to_string(n) + " given): its work memory is a fixed array");
 	if (!s->haveTris || !s->haveBvh) return fail(RTX_ERR_STATE, "rtx_scene_set_triangles and rtx_scene_set_bvh must come first");
-	if (!s->noallocScratch) return fail(RTX_ERR_STATE, "the scene has no scratch array");
+	if (!s->noallocScratch || !s->hNoallocFault) return fail(RTX_ERR_STATE, "the scene has no scratch array");
 	HIPCHK(hipSetDevice(s->device));
 	std::memset(&s->stats, 0, sizeof(s->stats));
 	if (n == 0) return RTX_OK;
@@ -1655,10 +1692,14 @@ RTX_API int rtx_trace_rays_noalloc(rtx_scene* s, int mode, uint32_t n, const flo
 	if (rc) return rc;
 	hipLaunchKernelGGL(k_export_hits_linear, dim3((n + 255) / 256), dim3(256), 0, s->stream, d, (int)n, hits, d_tri_ids, d_t_alpha_beta);
 	HIPCHK(hipGetLastError());
-	unsigned faultBits = 0;
-	HIPCHK(hipMemcpyAsync(&faultBits, counts + FAULT_WORD, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
-	HIPCHK(hipStreamSynchronize(s->stream));
-	rc = check_fault(faultBits);
+	// the fault word travels into the scene's own pinned word (never into a stack slot the copy could outlive); the
+	// wait below makes the call blocking, which is also why it cannot be part of a HIP graph capture
+	*s->hNoallocFault = 0;
+	hipError_t e = hipMemcpyAsync(s->hNoallocFault, counts + FAULT_WORD, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream);
+	const hipError_t eSync = hipStreamSynchronize(s->stream);  // also after a failed copy: nothing of this call stays in flight
+	if (e == hipSuccess) e = eSync;
+	if (e != hipSuccess) return fail(RTX_ERR_DEVICE, std::string("rtx_trace_rays_noalloc: ") + hipGetErrorString(e));
+	rc = check_fault(*s->hNoallocFault);
 	if (rc) return rc;
 	s->stats.rays = n;
 	s->stats.rays_per_level[0] = n;
@@ -1741,87 +1782,242 @@ int rccl_open(Rccl& r) {
 
 }  // namespace
 
-RTX_API int rtx_gather_tiles(rtx_scene* const* scenes, int n) {
-	if (!scenes || n < 1) return fail(RTX_ERR_ARG, "scenes is null or n < 1");
+namespace {
+
+// What one exchange moves: for every scene the tile numbers of its share, and for every sender the place of its
+// message in scene 0's receive buffer.  Scene 0's own share stays where it is, unless it is the only scene: a
+// single share travels to itself, so that one GPU can exercise every step.
+// Messages lie one behind the other in the order of the scenes: recvOffset[r] = TILE * TILE * (tiles of the senders
+// before r), in float4; recvTotal the same sum over all senders.
+struct ExchangePlan {
+	int firstSender = 1;
+	std::vector<std::vector<int>> ids;
+	std::vector<size_t> recvOffset;
+	size_t recvTotal = 0;
+};
+
+void plan_offsets(ExchangePlan& p) {
+	const int n = (int)p.ids.size();
+	p.firstSender = n == 1 ? 0 : 1;
+	p.recvOffset.assign((size_t)n, 0);
+	p.recvTotal = 0;
+	for (int r = p.firstSender; r < n; ++r) {
+		p.recvOffset[(size_t)r] = p.recvTotal;
+		p.recvTotal += p.ids[(size_t)r].size() * (size_t)(TILE * TILE);
+	}
+}
+
+// The tile numbers of a scene's current share (rtx_scene_set_tiles): first, first + stride, ...
+std::vector<int> share_ids(const rtx_scene* s) {
+	std::vector<int> ids;
+	const int n = tile_slots(s);
+	ids.reserve((size_t)std::max(n, 0));
+	for (int k = 0; k < n; ++k) ids.push_back(s->tileFirst + k * s->tileStride);
+	return ids;
+}
+
+int ensure_id_staging(rtx_scene* s, size_t count) {
+	if (s->hTileIdsCap >= count) return RTX_OK;
+	if (s->hTileIds) (void)hipHostFree(s->hTileIds);
+	s->hTileIds = nullptr;
+	s->hTileIdsCap = 0;
+	const size_t cap = std::max<size_t>(count, 4096);
+	HIPCHK(hipHostMalloc((void**)&s->hTileIds, cap * sizeof(int), hipHostMallocDefault));
+	s->hTileIdsCap = cap;
+	return RTX_OK;
+}
+
+// Pack on every sender, one message per sender to scene 0, unpack there.  Transport: RCCL (ncclSend / ncclRecv in
+// one group: one message per xGMI link, all at once) between different GPUs -- and for the single scene that sends
+// to itself --, a device-to-device copy where all scenes share one GPU.
+// add: scene 0 adds what it receives to its accumulator instead of overwriting it; clear: a sender's tiles are zero
+// afterwards.
+int run_exchange(rtx_scene* const* scenes, int n, ExchangePlan& plan, bool add, bool clear) {
 	rtx_scene* s0 = scenes[0];
-	for (int r = 0; r < n; ++r) {
-		rtx_scene* s = scenes[r];
-		if (!s) return fail(RTX_ERR_ARG, "a scene is null");
-		if (!s->haveParams || s->width != s0->width || s->height != s0->height) return fail(RTX_ERR_ARG, "the scenes differ in image size");
-		if (s->tileFirst != r || s->tileStride != n || s->tileCount >= 0)
-			return fail(RTX_ERR_ARG, "scene r must hold the tile share (r, n): rtx_scene_set_tiles(scenes[r], r, n, -1)");
-		for (int q = 0; q < r; ++q)
-			if (scenes[q]->device == s->device && n > 1) return fail(RTX_ERR_ARG, "two scenes of one exchange on the same GPU");
-		const int rc = ensure_ready(s, false);
-		if (rc) return rc;
-	}
-	std::lock_guard<std::mutex> lk(g_rcclMutex);
-	int rc = rccl_open(g_rccl);
-	if (rc) return rc;
-	std::vector<int> devices(n);
-	for (int r = 0; r < n; ++r) devices[r] = scenes[r]->device;
-	if (g_rccl.devices != devices) {
-		for (ncclComm_t c : g_rccl.comms)
-			if (c) (void)g_rccl.commDestroy(c);
-		g_rccl.comms.assign((size_t)n, nullptr);
-		g_rccl.devices.clear();
-		RCCLCHK(g_rccl.commInitAll(g_rccl.comms.data(), n, devices.data()));
-		g_rccl.devices = devices;
-	}
-	// a scene's own share stays where it is; with a single scene the share travels to itself, so that one GPU
-	// exercises every step of the exchange
-	const int firstSender = n == 1 ? 0 : 1;
+	plan_offsets(plan);
+	const int firstSender = plan.firstSender;
 	const int tilesX = (s0->width + TILE - 1) / TILE;
-	const size_t slotsMax = (size_t)(num_tiles(s0) + n - 1) / (size_t)n;  // the largest share
-	const size_t perShare = slotsMax * TILE * TILE;                       // float4 per message
+	const int numTiles = num_tiles(s0);
+	bool sameDevice = n > 1;
+	for (int r = 1; r < n; ++r) sameDevice = sameDevice && scenes[r]->device == s0->device;
+	if (!sameDevice)
+		for (int r = 0; r < n; ++r)
+			for (int q = 0; q < r; ++q)
+				if (scenes[q]->device == scenes[r]->device)
+					return fail(RTX_ERR_ARG, "the scenes of one exchange live either on n different GPUs or all on the same one");
+	for (int r = 0; r < n; ++r)
+		for (int t : plan.ids[(size_t)r])
+			if (t < 0 || t >= numTiles) return fail(RTX_ERR_ARG, "a tile number outside the image");
+	if (plan.recvTotal == 0) return RTX_OK;  // nothing to move
+
+	std::lock_guard<std::mutex> lk(g_rcclMutex);
+	if (!sameDevice) {
+		int rc = rccl_open(g_rccl);
+		if (rc) return rc;
+		std::vector<int> devices((size_t)n);
+		for (int r = 0; r < n; ++r) devices[(size_t)r] = scenes[r]->device;
+		if (g_rccl.devices != devices) {
+			for (ncclComm_t c : g_rccl.comms)
+				if (c) (void)g_rccl.commDestroy(c);
+			g_rccl.comms.assign((size_t)n, nullptr);
+			g_rccl.devices.clear();
+			RCCLCHK(g_rccl.commInitAll(g_rccl.comms.data(), n, devices.data()));
+			g_rccl.devices = devices;
+		}
+	}
+
+	// scene 0: room for every message and for the tile numbers that go with them
 	HIPCHK(hipSetDevice(s0->device));
-	if (s0->dTileRecv.n < perShare * (size_t)(n - firstSender)) HIPCHK(s0->dTileRecv.alloc(perShare * (size_t)(n - firstSender)));
+	if (s0->dTileRecv.n < plan.recvTotal) HIPCHK(s0->dTileRecv.alloc(plan.recvTotal));
+	const size_t recvIds = plan.recvTotal / (size_t)(TILE * TILE);
+	if (s0->dTileIdsRecv.n < recvIds) HIPCHK(s0->dTileIdsRecv.alloc(recvIds));
+	{
+		const size_t own = firstSender == 0 ? plan.ids[0].size() : 0;  // the single scene also packs: its own list comes first
+		int rc = ensure_id_staging(s0, own + recvIds);
+		if (rc) return rc;
+		int* stage = s0->hTileIds + own;
+		for (int r = firstSender; r < n; ++r)
+			std::copy(plan.ids[(size_t)r].begin(), plan.ids[(size_t)r].end(), stage + plan.recvOffset[(size_t)r] / (size_t)(TILE * TILE));
+		HIPCHK(hipMemcpyAsync(s0->dTileIdsRecv.p, stage, recvIds * sizeof(int), hipMemcpyHostToDevice, s0->stream));
+	}
+	// senders: tile numbers up, share packed
 	for (int r = firstSender; r < n; ++r) {
 		rtx_scene* s = scenes[r];
+		const std::vector<int>& ids = plan.ids[(size_t)r];
+		if (ids.empty()) continue;
 		HIPCHK(hipSetDevice(s->device));
-		if (s->dTilePack.n < perShare) HIPCHK(s->dTilePack.alloc(perShare));
-		const int slots = tile_slots(s);
-		if (slots > 0) {
-			hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)(((size_t)slots * TILE * TILE + 255) / 256)), dim3(256), 0, s->stream, s->dAccum,
-							   s->width, s->height, tilesX, s->tileFirst, s->tileStride, slots, s->dTilePack.p);
-			RTX_LAUNCHED("k_pack_tiles");
-			// RTX_GATHER_POISON=1 (tests, single scene only): what was packed is wiped from the image, so the image is
-			// whole again only if pack, send, receive and unpack all did their part
-			if (n == 1 && std::getenv("RTX_GATHER_POISON"))
-				HIPCHK(hipMemsetAsync(s->dAccum, 0xFF, (size_t)s->width * s->height * sizeof(float4), s->stream));
+		const size_t count = ids.size() * (size_t)(TILE * TILE);
+		if (s->dTilePack.n < count) HIPCHK(s->dTilePack.alloc(count));
+		if (s->dTileIds.n < ids.size()) HIPCHK(s->dTileIds.alloc(ids.size()));
+		int rc = ensure_id_staging(s, ids.size() + (r == 0 ? recvIds : 0));
+		if (rc) return rc;
+		std::copy(ids.begin(), ids.end(), s->hTileIds);
+		HIPCHK(hipMemcpyAsync(s->dTileIds.p, s->hTileIds, ids.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s->stream, s->dAccum, s->width, s->height, tilesX,
+						   (const int*)s->dTileIds.p, (int)ids.size(), numTiles, s->dTilePack.p, clear ? 1 : 0);
+		RTX_LAUNCHED("k_pack_tiles");
+		// RTX_GATHER_POISON=1 (tests, single scene only): what was packed is wiped from the image, so the image is
+		// whole again only if pack, send, receive and unpack all did their part
+		if (n == 1 && std::getenv("RTX_GATHER_POISON"))
+			HIPCHK(hipMemsetAsync(s->dAccum, 0xFF, (size_t)s->width * s->height * sizeof(float4), s->stream));
+		if (sameDevice) {
+			if (!s->exchEvent) HIPCHK(hipEventCreateWithFlags(&s->exchEvent, hipEventDisableTiming));
+			HIPCHK(hipEventRecord(s->exchEvent, s->stream));
 		}
 	}
-	// one message per peer, all in one group: every peer's share crosses its own link to GPU 0 at the same time
-	RCCLCHK(g_rccl.groupStart());
-	for (int r = firstSender; r < n; ++r) {
-		rtx_scene* s = scenes[r];
-		const size_t count = (size_t)tile_slots(s) * TILE * TILE * 4;  // floats
-		if (!count) continue;
-		ncclResult_t a = g_rccl.send(s->dTilePack.p, count, ncclFloat, 0, g_rccl.comms[r], s->stream);
-		ncclResult_t b = a == ncclSuccess ? g_rccl.recv(s0->dTileRecv.p + perShare * (size_t)(r - firstSender), count, ncclFloat, r, g_rccl.comms[0], s0->stream) : a;
-		if (b != ncclSuccess) {
-			(void)g_rccl.groupEnd();
-			return fail(RTX_ERR_DEVICE, std::string("ncclSend/ncclRecv: ") + g_rccl.errorString(b));
+	if (sameDevice) {
+		// every message is a copy inside the one GPU, ordered behind its sender's pack
+		HIPCHK(hipSetDevice(s0->device));
+		for (int r = firstSender; r < n; ++r) {
+			rtx_scene* s = scenes[r];
+			const size_t count = plan.ids[(size_t)r].size() * (size_t)(TILE * TILE);
+			if (!count) continue;
+			HIPCHK(hipStreamWaitEvent(s0->stream, s->exchEvent, 0));
+			HIPCHK(hipMemcpyAsync(s0->dTileRecv.p + plan.recvOffset[(size_t)r], s->dTilePack.p, count * sizeof(float4), hipMemcpyDeviceToDevice, s0->stream));
 		}
 	}
-	RCCLCHK(g_rccl.groupEnd());
+	else {
+		// one message per peer, all in one group: every peer's share crosses its own link to GPU 0 at the same time
+		RCCLCHK(g_rccl.groupStart());
+		for (int r = firstSender; r < n; ++r) {
+			rtx_scene* s = scenes[r];
+			const size_t count = plan.ids[(size_t)r].size() * (size_t)(TILE * TILE) * 4;  // floats
+			if (!count) continue;
+			ncclResult_t a = g_rccl.send(s->dTilePack.p, count, ncclFloat, 0, g_rccl.comms[(size_t)r], s->stream);
+			ncclResult_t b = a == ncclSuccess ? g_rccl.recv(s0->dTileRecv.p + plan.recvOffset[(size_t)r], count, ncclFloat, r, g_rccl.comms[0], s0->stream) : a;
+			if (b != ncclSuccess) {
+				(void)g_rccl.groupEnd();
+				return fail(RTX_ERR_DEVICE, std::string("ncclSend/ncclRecv: ") + g_rccl.errorString(b));
+			}
+		}
+		RCCLCHK(g_rccl.groupEnd());
+	}
 	HIPCHK(hipSetDevice(s0->device));
 	for (int r = firstSender; r < n; ++r) {
-		rtx_scene* s = scenes[r];
-		const int slots = tile_slots(s);
-		if (slots <= 0) continue;
-		rtx_scene* sdst = s0;
-		{
-			rtx_scene* s = sdst;  // the launch check reports on the receiving scene's stream
-			hipLaunchKernelGGL(k_unpack_tiles, dim3((unsigned)(((size_t)slots * TILE * TILE + 255) / 256)), dim3(256), 0, s->stream, s->dAccum,
-							   s->width, s->height, tilesX, r, n, slots, s->dTileRecv.p + perShare * (size_t)(r - firstSender));
-			RTX_LAUNCHED("k_unpack_tiles");
-		}
+		const size_t slots = plan.ids[(size_t)r].size();
+		if (!slots) continue;
+		rtx_scene* s = s0;  // the launch check reports on the receiving scene
+		hipLaunchKernelGGL(k_unpack_tiles, dim3((unsigned)((slots * TILE * TILE + 255) / 256)), dim3(256), 0, s->stream, s->dAccum, s->width, s->height, tilesX,
+						   (const int*)(s->dTileIdsRecv.p + plan.recvOffset[(size_t)r] / (size_t)(TILE * TILE)), (int)slots, numTiles,
+						   (const float4*)(s->dTileRecv.p + plan.recvOffset[(size_t)r]), add ? 1 : 0);
+		RTX_LAUNCHED("k_unpack_tiles");
 	}
 	for (int r = n - 1; r >= 0; --r) {
 		HIPCHK(hipSetDevice(scenes[r]->device));
 		HIPCHK(hipStreamSynchronize(scenes[r]->stream));
 	}
+	return RTX_OK;
+}
+
+int check_exchange_scenes(rtx_scene* const* scenes, int n) {
+	if (!scenes || n < 1) return fail(RTX_ERR_ARG, "scenes is null or n < 1");
+	rtx_scene* s0 = scenes[0];
+	for (int r = 0; r < n; ++r) {
+		rtx_scene* s = scenes[r];
+		if (!s) return fail(RTX_ERR_ARG, "a scene is null");
+		for (int q = 0; q < r; ++q)
+			if (scenes[q] == s) return fail(RTX_ERR_ARG, "the same scene twice in one exchange");
+		if (!s->haveParams || !s0->haveParams || s->width != s0->width || s->height != s0->height) return fail(RTX_ERR_ARG, "the scenes differ in image size");
+		const int rc = ensure_ready(s, false);
+		if (rc) return rc;
+	}
+	return RTX_OK;
+}
+
+}  // namespace
+
+RTX_API int rtx_gather_tiles(rtx_scene* const* scenes, int n) {
+	int rc = check_exchange_scenes(scenes, n);
+	if (rc) return rc;
+	ExchangePlan plan;
+	plan.ids.resize((size_t)n);
+	for (int r = 0; r < n; ++r) {
+		const rtx_scene* s = scenes[r];
+		if (s->tileFirst != r || s->tileStride != n || s->tileCount >= 0)
+			return fail(RTX_ERR_ARG, "scene r must hold the tile share (r, n): rtx_scene_set_tiles(scenes[r], r, n, -1)");
+		plan.ids[(size_t)r] = share_ids(s);
+	}
+	return run_exchange(scenes, n, plan, false, false);
+}
+
+RTX_API int rtx_exchange_tiles(rtx_scene* const* scenes, int n) {
+	int rc = check_exchange_scenes(scenes, n);
+	if (rc) return rc;
+	const int total = num_tiles(scenes[0]);
+	ExchangePlan plan;
+	plan.ids.resize((size_t)n);
+	std::vector<int> owner((size_t)total, -1);
+	for (int r = 0; r < n; ++r) {
+		const rtx_scene* s = scenes[r];
+		for (int t = 0; t < (int)s->tileLog.size() && t < total; ++t) {
+			if (!s->tileLog[(size_t)t]) continue;
+			if (owner[(size_t)t] >= 0)
+				return fail(RTX_ERR_ARG, "tile " + std::to_string(t) + " was rendered by scenes " + std::to_string(owner[(size_t)t]) + " and " + std::to_string(r) +
+											 " since the last exchange: a frame's tiles must be shared out without overlap");
+			owner[(size_t)t] = r;
+			plan.ids[(size_t)r].push_back(t);
+		}
+	}
+	rc = run_exchange(scenes, n, plan, true, true);
+	if (rc) return rc;
+	for (int r = 0; r < n; ++r) std::fill(scenes[r]->tileLog.begin(), scenes[r]->tileLog.end(), 0);
+	return RTX_OK;
+}
+
+RTX_API int rtx_scene_tile_log(rtx_scene* s, int* tiles, int capacity) {
+	if (!s || (capacity > 0 && !tiles) || capacity < 0) return fail(RTX_ERR_ARG, "bad argument");
+	int n = 0;
+	for (size_t t = 0; t < s->tileLog.size(); ++t)
+		if (s->tileLog[t]) {
+			if (n < capacity) tiles[n] = (int)t;
+			++n;
+		}
+	return n;
+}
+
+RTX_API int rtx_scene_tile_log_clear(rtx_scene* s) {
+	if (!s) return fail(RTX_ERR_ARG, "scene is null");
+	std::fill(s->tileLog.begin(), s->tileLog.end(), 0);
 	return RTX_OK;
 }
 

@@ -10,10 +10,12 @@ path of a frame.  One exchange step produces the image on rank 0:
           every rank packs the accumulators of its own tiles (one index_select over a cached pixel
           index) and rank 0 receives them with one gather -- each peer sends only its 1/world of the
           image over its own direct link -- and scatters them into the image with one index_copy.
-  dynamic ranks pull batches of tiles from a shared counter (the rendezvous store's atomic add),
-          render each frame into a zeroed frame buffer, and the frame buffers are sum-reduced to
-          rank 0, which adds the frame to its accumulator.  Every pixel is non-zero on exactly one
-          rank, and x + 0 is exact, so the result is bit-identical to a single-GPU run.
+  dynamic ranks pull batches of tiles from a shared counter (the rendezvous store's atomic add).  Rank 0
+          renders straight into the accumulator; every other rank renders a frame into a buffer that is
+          empty between frames and sends rank 0 the tiles it rendered -- their numbers and their packed
+          pixels in one message, as much data as the static gather moves -- which rank 0 adds to the
+          accumulator.  A zeroed buffer plus one frame's contribution is that contribution exactly, so
+          accumulator + message is bit for bit what rendering the tile on rank 0 would have given.
 """
 import math
 
@@ -70,10 +72,12 @@ class TileSharder:
             cache[key] = (pack, place)
         return cache[key]
 
-    def gather_static(self, accum):
+    def gather_static(self, accum, force_collective=False):
         """accum: (H,W,4) tensor holding this rank's tiles.  Returns the whole image on rank 0, None elsewhere.
-        One packing gather per rank, one collective, one scatter on rank 0."""
-        if self.world == 1:
+        One packing gather per rank, one collective, one scatter on rank 0.  force_collective: do all of it even in
+        a world of one, where it moves the image onto itself (a one-rank RCCL group on a single GPU then runs the
+        very calls a run on several GPUs makes)."""
+        if self.world == 1 and not force_collective:
             return accum
         c = accum.shape[-1]
         n_pix = self.width * self.height
@@ -104,14 +108,70 @@ class TileSharder:
                 return
             yield start, min(batch, self.n_tiles - start)
 
-    def reduce_frame(self, frame_buf, accum_total):
-        """Sum-reduces the per-frame buffers to rank 0 and adds the frame to rank 0's accumulator."""
-        if self.world > 1:
-            dist.reduce(frame_buf, dst=0, op=dist.ReduceOp.SUM, group=self.group)
-        if self.rank == 0:
-            accum_total += frame_buf
+    def _tile_pixels(self, tiles, device):
+        """Flat pixel indices of the TILE x TILE slots of `tiles` (int64 tensor on `device`) and which of them lie
+        inside the image."""
+        ar = torch.arange(TILE, device=device)
+        ty, tx = tiles // self.tiles_x, tiles % self.tiles_x
+        yy = (ty[:, None, None] * TILE + ar[None, :, None]).expand(len(tiles), TILE, TILE)
+        xx = (tx[:, None, None] * TILE + ar[None, None, :]).expand(len(tiles), TILE, TILE)
+        valid = ((yy < self.height) & (xx < self.width)).reshape(-1)
+        return (yy * self.width + xx).reshape(-1), valid
+
+    def exchange_dynamic(self, tiles, frame_buf, accum_total, force_collective=False):
+        """One frame of the dynamic scheme.  tiles: the tile numbers this rank rendered this frame -- ranks > 0 into
+        frame_buf (H,W,4), which holds nothing else, rank 0 straight into accum_total.  Ranks > 0 send (tile numbers,
+        packed pixels) in one message each and leave frame_buf empty again; rank 0 adds what arrives to accum_total
+        and returns it.  Messages have the ranks' own lengths: a one-int all_gather tells rank 0 what to expect.
+        force_collective: run the collective calls even in a world of one (a one-rank RCCL group on a single GPU
+        then exercises the call path of several)."""
+        if self.world == 1 and not force_collective:
             return accum_total
-        return None
+        ref = accum_total if self.rank == 0 else frame_buf
+        device = ref.device
+        c = ref.shape[-1]
+        n_pix = self.width * self.height
+        tiles = torch.as_tensor(tiles, dtype=torch.int64).reshape(-1)
+        backend = dist.get_backend(self.group)
+        staged = device.type == "cuda" and backend == "gloo"   # gloo moves host tensors (rehearsals on one GPU)
+        wire = torch.device("cpu") if staged else device
+        counts = torch.zeros(self.world, dtype=torch.int64, device=wire)
+        mine = torch.tensor([0 if self.rank == 0 else len(tiles)], dtype=torch.int64, device=wire)
+        dist.all_gather_into_tensor(counts, mine, group=self.group)
+        counts = counts.tolist()
+        per_tile = TILE * TILE * c
+        if self.rank != 0:
+            if len(tiles):
+                td = tiles.to(device)
+                idx, valid = self._tile_pixels(td, device)
+                flat = frame_buf.reshape(n_pix, c)
+                data = flat.index_select(0, idx.clamp(max=n_pix - 1))
+                flat[idx[valid]] = 0          # empty again for the next frame
+                msg = torch.cat([data.reshape(-1), td.to(torch.int32).view(torch.float32)])
+                if staged:
+                    msg = msg.cpu()
+                dist.send(msg, dst=0, group=self.group)
+            return None
+        bufs, ops = {}, []
+        for r in range(1, self.world):
+            if counts[r]:
+                bufs[r] = torch.empty(counts[r] * (per_tile + 1), dtype=torch.float32, device=wire)
+                ops.append(dist.P2POp(dist.irecv, bufs[r], r, self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        flat = accum_total.reshape(n_pix, c)
+        for r, buf in bufs.items():
+            buf = buf.to(device) if staged else buf
+            k = counts[r]
+            ids = buf[k * per_tile:].view(torch.int32).to(torch.int64)
+            if ids.numel() != k or int(ids.min()) < 0 or int(ids.max()) >= self.n_tiles:
+                raise RuntimeError("rank %d sent tile numbers outside the image" % r)
+            idx, valid = self._tile_pixels(ids, device)
+            data = buf[:k * per_tile].reshape(-1, c)
+            where = idx[valid]
+            flat[where] = flat[where] + data[valid]      # every pixel once per frame: a plain x = x + contribution
+        return accum_total
 
 
 def default_store():

@@ -34,24 +34,26 @@ def main():
         rt.render(1, frames)
         torch.cuda.synchronize()
         img = sh.gather_static(accum)
-        # dynamic balancing: tile batches from the shared counter, per-frame buffers sum-reduced to rank 0
+        # dynamic balancing: tile batches from the shared counter; rank 0 renders into the accumulator, the other
+        # rank into a frame buffer whose rendered tiles (the library's own log of them) travel to rank 0 every frame
         store = default_store()
         total = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
         buf = torch.zeros_like(total)
-        rt.set_accum_device(buf.data_ptr())
+        rt.set_accum_device((total if rank == 0 else buf).data_ptr())
+        rt.clear_tile_log()
         res = None
         for f in range(1, frames + 1):
-            buf.zero_()
-            torch.cuda.synchronize()
+            pulled = []
             for first, count in sh.dynamic_batches(store, f, 2):
                 rt.set_tiles(first, 1, count)
                 rt.render(f, 1)
+                pulled += list(range(first, first + count))
+            tiles = rt.tile_log()
+            assert tiles.tolist() == sorted(pulled)
+            rt.clear_tile_log()
+            res = sh.exchange_dynamic(tiles, buf, total)
             torch.cuda.synchronize()
-            host = buf.cpu()                       # gloo reduces host tensors
-            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-            if rank == 0:
-                total += host.to(dev)
-                res = total
+            assert rank == 0 or not bool(buf.any())
         if rank == 0:
             np.save(out + "_static.npy", img.cpu().numpy())
             np.save(out + "_dynamic.npy", res.cpu().numpy())

@@ -1,6 +1,6 @@
 """The multi-rank exchange (raytracer_amd/dist.py) with world_size 2 on the gloo backend, CPU only.
 Rendering is replaced by a deterministic per-pixel function so that the test exercises exactly the
-sharding logic: static tile interleave + gather, and dynamic batches + sum-reduce."""
+sharding logic: static tile interleave + gather, and dynamic batches + a gather of the tiles each rank rendered."""
 import os
 import socket
 
@@ -49,17 +49,22 @@ def worker(rank, world, port, out):
         for f in (1, 2, 3):
             acc += fake_render(f, mine, sh.tiles_x)
         img = sh.gather_static(acc)
-        # dynamic: tiles pulled from the shared counter, frame buffers reduced
+        # dynamic: tiles pulled from the shared counter; rank 0 renders into the accumulator, the others into a
+        # frame buffer whose tiles (numbers + pixels) travel to rank 0 and are added there
         store = default_store()
         total = torch.zeros((H, W, 4), dtype=torch.float32)
+        buf = torch.zeros((H, W, 4), dtype=torch.float32)
         pulled = 0
         for f in (1, 2, 3):
-            buf = torch.zeros((H, W, 4), dtype=torch.float32)
+            tiles = []
             for start, count in sh.dynamic_batches(store, f, 2):
-                buf += fake_render(f, range(start, start + count), sh.tiles_x)
+                target = total if rank == 0 else buf
+                target += fake_render(f, range(start, start + count), sh.tiles_x)
+                tiles += list(range(start, start + count))
                 pulled += count
             dist.barrier()
-            res = sh.reduce_frame(buf, total)
+            res = sh.exchange_dynamic(tiles, buf, total)
+            assert rank == 0 or not buf.any()          # a sender's buffer is empty again
         cnt = torch.tensor([pulled])
         dist.all_reduce(cnt)
         if rank == 0:
@@ -72,7 +77,7 @@ def worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_two_rank_static_gather_and_dynamic_reduce(tmp_path):
+def test_two_rank_static_gather_and_dynamic_exchange(tmp_path):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -115,3 +120,30 @@ def test_static_plan_with_uneven_shares():
     out = torch.empty((n_pix + 1, 4))
     out.index_copy_(0, place, torch.cat(sends))
     assert torch.equal(out[:n_pix].reshape(H, W, 4), img)
+
+
+def one_rank_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sh = TileSharder(W, H, 0, 1)
+        acc = fake_render(1, range(sh.n_tiles), sh.tiles_x)
+        img = sh.gather_static(acc.clone(), force_collective=True)      # the collective calls in a world of one
+        same = sh.exchange_dynamic(list(range(sh.n_tiles)), None, acc.clone(), force_collective=True)
+        np.save(out + "_one.npy", np.stack([acc.numpy(), img.numpy(), same.numpy()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collective_path_in_a_world_of_one(tmp_path):
+    """force_collective runs pack -> gather -> place (and the count exchange of the dynamic scheme) with a single
+    rank: the image must come back unchanged.  The GPU suite does the same over a one-rank RCCL group."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "img")
+    mp.spawn(one_rank_worker, args=(1, port, out), nprocs=1, join=True)
+    a, b, c = np.load(out + "_one.npy")
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(a.view(np.uint32), c.view(np.uint32))

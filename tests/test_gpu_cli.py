@@ -183,6 +183,26 @@ render_num %d
     for i in range(1, frames + 1):
         assert open(os.path.join(d, "out_%03d.png" % i), "rb").read() == first[i - 1], "frame %d differs after the exchange" % i
 
+    # Several workers in one process, as on a node with several GPUs, here all on the one GPU of the box (RTX_DEVICE_MAP:
+    # their tiles then meet by a copy inside the GPU, every other step is the one several GPUs take): a 200 x 150 frame
+    # has 4 x 3 tiles, the last column and row partial.  Dynamic balancing (an interleaved head, the rest of the tiles
+    # pulled in batches from one atomic counter by whichever worker comes first; rtx_exchange_tiles adds every
+    # frame's tiles to worker 0's accumulator), dynamic with every tile pulled, and the static interleave
+    # (rtx_gather_tiles) must all write the files one worker writes.
+    open(os.path.join(d, "config.txt"), "w").write(cfg.replace("frame %d %d" % (W, H), "frame 200 150"))
+    res = subprocess.run([build.CLI_BIN, "config.txt"], cwd=d, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and "Render finished" in res.stdout, res.stdout + res.stderr
+    one = [open(os.path.join(d, "out_%03d.png" % i), "rb").read() for i in range(1, frames + 1)]
+    assert read_png(os.path.join(d, "out_%03d.png" % frames)).shape == (150, 200, 3)
+    for workers, extra in ((2, {}), (2, {"RTX_DYNAMIC_PERCENT": "100"}), (3, {"RTX_BALANCE": "static"}), (5, {"RTX_DYNAMIC_PERCENT": "60"})):
+        for i in range(1, frames + 1):
+            os.remove(os.path.join(d, "out_%03d.png" % i))
+        env = dict(os.environ, RTX_DEVICES=str(workers), RTX_DEVICE_MAP=",".join(["0"] * workers), **extra)
+        res = subprocess.run([build.CLI_BIN, "config.txt"], cwd=d, capture_output=True, text=True, timeout=180, env=env)
+        assert res.returncode == 0 and "Render finished" in res.stdout, res.stdout + res.stderr
+        for i in range(1, frames + 1):
+            assert open(os.path.join(d, "out_%03d.png" % i), "rb").read() == one[i - 1], "%d workers %s: frame %d differs" % (workers, extra, i)
+
 
 def ball_mesh(rings, segs, radius, seed):
     """Indexed lat-long ball with a little relief, open by a hair at the poles (no zero-area faces), radial normals."""

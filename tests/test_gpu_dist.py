@@ -1,7 +1,7 @@
 """The N > 1 flow with real rendered tiles: two processes share the one GPU of the box (gloo backend, so the exchange
 travels through the host; on a node with several GPUs the same code runs over RCCL), each renders its tile share of a
-small scene with the HIP library, the shares are gathered (static interleave) or sum-reduced (dynamic batches) to rank
-0, and the image must equal the single-process image bit for bit."""
+small scene with the HIP library, the shares are gathered (static interleave) or, tile by rendered tile, added on rank 0
+(dynamic batches), and the image must equal the single-process image bit for bit."""
 import os
 import socket
 import subprocess
@@ -49,4 +49,29 @@ def test_two_processes_render_real_tile_shares_and_exchange_them(tmp_path):
                 p.kill()
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-3000:]
     assert_bits_equal(want, np.load(out + "_static.npy"), "static interleave + gather, two ranks")
-    assert_bits_equal(want, np.load(out + "_dynamic.npy"), "dynamic batches + reduce, two ranks")
+    assert_bits_equal(want, np.load(out + "_dynamic.npy"), "dynamic batches + exchange of the rendered tiles, two ranks")
+
+
+def test_exchange_calls_over_a_one_rank_rccl_group(tmp_path):
+    """The RCCL call path of bench.py --gpus N on one GPU: a process group of one rank on backend nccl, the static gather
+    and the dynamic scheme forced through their collective calls (device tensors, dist.gather,
+    all_gather_into_tensor).  The image must come back as it went in, and equal the image rendered without torch."""
+    sc = scenes.mixed_scene(seed=5, width=W, height=H, max_depth=3, n_diff=2, n_spec=1, with_sky=True)
+    rt = api.RayTracer(0)
+    rt.load_scene(sc)
+    rt.reset()
+    rt.render(1, 2)
+    want = rt.accum()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "img")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "nccl_one_rank_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, worker, out, str(W), str(H)], env=env, capture_output=True, text=True, timeout=170)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    before, gathered, dynamic = np.load(out + "_nccl.npy")
+    assert_bits_equal(want, before, "rendered into a torch tensor")
+    assert_bits_equal(want, gathered, "gather_static over a one-rank RCCL group")
+    assert_bits_equal(want, dynamic, "exchange_dynamic over a one-rank RCCL group")

@@ -16,7 +16,7 @@ import pytest
 from oracle import binding
 from raytracer_amd import api, scenes
 from scene_io import load_fixture, oracle_from_fixture, scene_from_fixture
-from util import assert_bits_equal, bits, load_into
+from util import assert_bits_equal, assert_pixels_equal, bits, load_into, scattered_blocks
 
 pytestmark = pytest.mark.gpu
 
@@ -323,8 +323,8 @@ def test_atrium_tiles_arena_and_determinism(libs):
 
 
 def test_atrium_full_size_rows_equal_restatement(libs):
-    """The benchmark workload itself (atrium, 1920x1080, depth 4, two frames): three rows of the accumulator
-    against the CPU restatement, the frame's ray count against the per-level counts, and the device tone map of
+    """The benchmark workload itself (atrium, 1920x1080, depth 4, two frames): 360 scattered 4x4-pixel blocks of the
+    accumulator against the CPU restatement, the frame's ray count against the per-level counts, and the device tone map of
     the whole frame against the host's."""
     sc = scenes.atrium_scene(width=1920, height=1080, max_depth=4)
     nodes = api.build_bvh(sc.tris)
@@ -339,17 +339,17 @@ def test_atrium_full_size_rows_equal_restatement(libs):
     O = binding.Oracle()
     load_into(O, sc, build=False)
     O.set_nodes(nodes)
-    acc_o = np.zeros((sc.height, sc.width, 4), np.float32)
-    for f in (1, 2):
-        O.render_rows(f, acc_o, row0=539, row1=542, nthreads=16)
-    assert_bits_equal(acc_o[539:542, :, :3], full[539:542, :, :3], "rows 539..541 vs CPU")
+    # 360 blocks of 4x4 pixels scattered over the whole frame (sky at the top, floor at the bottom, tile seams, the
+    # image's corners and edges), the CPU time of three rows
+    xy = scattered_blocks(sc.width, sc.height, 360, seed=1080)
+    assert_pixels_equal(O, (1, 2), xy, full, "360 scattered 4x4 blocks vs CPU")
     assert np.array_equal(rt.tonemap_read(2).reshape(-1, 3), api.tonemap(full, 2))
 
 
 def test_atrium_4k_tile_shares_compose(libs):
     """The 4K multi-GPU configuration on one GPU: 3840x2160, depth 4, the image as one share, as two interleaved
     shares, and as a 1/8 share rendered for two frames in one call (merged batches) against the same share frame by
-    frame; a window against the CPU restatement."""
+    frame; 480 scattered 4x4-pixel blocks against the CPU restatement."""
     sc = scenes.atrium_scene(width=3840, height=2160, max_depth=4)
     nodes = api.build_bvh(sc.tris)
     rt = api.RayTracer(0)
@@ -386,9 +386,8 @@ def test_atrium_4k_tile_shares_compose(libs):
     O = binding.Oracle()
     load_into(O, sc, build=False)
     O.set_nodes(nodes)
-    acc_o = np.zeros((sc.height, sc.width, 4), np.float32)
-    O.render_rows(1, acc_o, row0=1079, row1=1081, nthreads=16)
-    assert_bits_equal(acc_o[1079:1081, :, :3], full[1079:1081, :, :3], "rows 1079..1080 vs CPU")
+    xy = scattered_blocks(sc.width, sc.height, 480, seed=2160)
+    assert_pixels_equal(O, (1,), xy, full, "480 scattered 4x4 blocks vs CPU")
 
 
 def test_converged_image_matches_mt19937_sampling(libs):
@@ -606,8 +605,8 @@ def test_ten_million_triangles_4k_depth_8(libs):
     """The stress configuration at its named size: a displaced mesh of more than ten million triangles,
     3840x2160, max_recursion_depth 8 (a gigabyte of nodes and triangle records: beyond the Infinity Cache).
     Culled traversal == exhaustive traversal on every one of the 33 million primary samples; the frame's ray
-    count is the sum of its levels' and no pixel batch had to be rendered twice; two rows of the accumulator ==
-    the CPU restatement of the reference."""
+    count is the sum of its levels' and no pixel batch had to be rendered twice; 480 4x4-pixel blocks scattered over
+    the accumulator == the CPU restatement of the reference."""
     sc = scenes.heightfield_scene(n_tris=10100000, width=3840, height=2160)
     assert len(sc.tris) >= 10000000
     sc.max_depth = 8
@@ -636,10 +635,9 @@ def test_ten_million_triangles_4k_depth_8(libs):
     O = binding.Oracle()
     load_into(O, sc, build=False)
     O.set_nodes(nodes)
-    acc_o = np.zeros((sc.height, sc.width, 4), np.float32)
-    O.render_rows(1, acc_o, row0=1200, row1=1202, nthreads=16)
-    assert full[1200:1202, :, :3].any()
-    assert_bits_equal(acc_o[1200:1202, :, :3], full[1200:1202, :, :3], "rows 1200..1201 vs CPU")
+    xy = scattered_blocks(sc.width, sc.height, 480, seed=10100000)
+    assert full[xy[:, 1], xy[:, 0], :3].any()
+    assert_pixels_equal(O, (1,), xy, full, "480 scattered 4x4 blocks vs CPU")
     # the second frame sizes its queues from the first one's populations and still needs no second try
     rt.render(2, 1)
     assert rt.stats()["queue_retries"] == 0
@@ -745,6 +743,64 @@ def test_tile_exchange_over_rccl_on_one_gpu(libs, monkeypatch):
     with pytest.raises(api.RtxError) as e:
         api.gather_tiles([rt])
     assert e.value.code == -1 and "tile share" in str(e.value)
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_tile_exchange_between_n_scenes_on_one_gpu(libs, n):
+    """The exchange of several GPUs in one process with n > 1, as far as one GPU can run it: n scenes on the one GPU,
+    scene r rendering the share (r, n) of a ragged image (4 x 3 tiles, shares of unequal size for n = 8), then
+    rtx_gather_tiles -- the plan of tile lists and receive offsets, k_pack_tiles on every sender, one message per
+    sender (a copy inside the GPU where RCCL would cross a link), k_unpack_tiles from the offsets of the plan.  Scene
+    0's image must equal the single-scene image.  Then the dynamic scheme on the same scenes: every frame's tiles
+    dealt out in uneven runs, rtx_exchange_tiles after every frame; scene 0's accumulator again equals the
+    single-scene one, and the senders' images are empty afterwards."""
+    sc = scenes.mixed_scene(seed=4, width=200, height=150)
+    one = gpu_scene(sc)
+    one.reset()
+    one.render(1, 2)
+    want = one.accum()
+    rts = [gpu_scene(sc) for _ in range(n)]
+    for r, rt in enumerate(rts):
+        rt.set_tiles(r, n, -1)
+        rt.reset()
+        rt.render(1, 2)
+    assert not np.array_equal(bits(rts[0].accum()), bits(want))        # scene 0 holds its share only
+    api.gather_tiles(rts)
+    assert_bits_equal(want, rts[0].accum(), "static shares gathered to scene 0")
+    api.gather_tiles(rts)
+    assert_bits_equal(want, rts[0].accum(), "second gather")
+    with pytest.raises(api.RtxError) as e:
+        api.gather_tiles(rts[1:] + rts[:1])                              # scene r must hold share (r, n)
+    assert e.value.code == -1
+    # dynamic: runs of 1, 2, 3, ... tiles go to the scenes in a different rotation every frame
+    n_tiles = 12
+    for rt in rts:
+        rt.reset()
+    for frame in (1, 2, 3):
+        first, k, run = 0, frame, 1
+        while first < n_tiles:
+            count = min(run, n_tiles - first)
+            rts[k % n].set_tiles(first, 1, count)
+            rts[k % n].render(frame, 1)
+            first += count
+            k += 1
+            run = run % 3 + 1
+        assert sum(len(rt.tile_log()) for rt in rts) == n_tiles
+        api.exchange_tiles(rts)
+        assert all(len(rt.tile_log()) == 0 for rt in rts)
+    one.reset()
+    one.render(1, 3)
+    assert_bits_equal(one.accum(), rts[0].accum(), "dynamic frames added on scene 0")
+    for rt in rts[1:]:
+        assert not rt.accum().any(), "a sender's frame buffer is empty after the exchange"
+    # a tile rendered by two scenes in one frame is refused
+    rts[0].set_tiles(0, 1, 2)
+    rts[0].render(4, 1)
+    rts[1].set_tiles(1, 1, 2)
+    rts[1].render(4, 1)
+    with pytest.raises(api.RtxError) as e:
+        api.exchange_tiles(rts)
+    assert e.value.code == -1 and "tile 1" in str(e.value)
 
 
 def test_device_tonemap_equals_host(libs):

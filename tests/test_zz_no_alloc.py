@@ -1,7 +1,7 @@
 """rtx_trace_rays_noalloc, the entry point that allocates nothing (its work memory is a fixed array inside the
 library), against rtx_trace_rays on the same rays: triangle ids exactly, t/alpha/beta bit for bit, on two calls in
 a row of which the second is smaller (the array keeps the first call's contents), in both traversal modes, plus
-the size limit.  Needs an MI355X: run with -m gpu."""
+the size limit, and free device memory (hipMemGetInfo) the same before and after every call.  Needs an MI355X: run with -m gpu."""
 import numpy as np
 import pytest
 
@@ -41,7 +41,9 @@ def test_noalloc_equals_trace_rays():
         ids_d.fill_(-7)
         tab_d.fill_(float("nan"))
         torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info(dev)[0]      # hipMemGetInfo: what the driver has left on the device
         rt.trace_rays_noalloc(n, o_d.data_ptr(), d_d.data_ptr(), ids_d.data_ptr(), tab_d.data_ptr(), mode)
+        assert torch.cuda.mem_get_info(dev)[0] == free_before, "the call changed the device's free memory"
         got_ids = ids_d[:n].cpu().numpy()
         got_tab = tab_d[:n].cpu().numpy()
         assert np.array_equal(got_ids, want_ids), "n=%d mode=%d: %d ids differ" % (n, mode, (got_ids != want_ids).sum())

@@ -61,3 +61,40 @@ def assert_bits_equal(a, b, what=""):
         idx = np.argwhere(neq)[:8]
         raise AssertionError("%s: %d of %d values differ; first at %s: %s vs %s" % (
             what, int(neq.sum()), a.size, idx.tolist(), a[neq][:8], b[neq][:8]))
+
+
+def scattered_blocks(width, height, n_blocks, seed, block=4):
+    """(n, 2) int32 pixel list (col, row): n_blocks seeded block x block squares spread over the whole image -- its
+    corners and edges always among them -- for comparing a large frame with the CPU at the price of a few rows."""
+    rng = np.random.default_rng(seed)
+    bx = rng.integers(0, max(1, width - block + 1), n_blocks)
+    by = rng.integers(0, max(1, height - block + 1), n_blocks)
+    fixed = [(0, 0), (width - block, 0), (0, height - block), (width - block, height - block),
+             (width // 2, 0), (width // 2, height - block), (0, height // 2), (width - block, height // 2)]
+    for k, (x, y) in enumerate(fixed[:n_blocks]):
+        bx[k], by[k] = max(0, x), max(0, y)
+    # no pixel twice: a block list is a set of block origins on distinct positions
+    seen, keep = set(), []
+    for x, y in zip(bx.tolist(), by.tolist()):
+        key = (x // block, y // block)
+        if key in seen:
+            continue
+        seen.add(key)
+        keep.append((x - x % block, y - y % block))
+    out = []
+    for x0, y0 in keep:
+        for dy in range(block):
+            for dx in range(block):
+                if x0 + dx < width and y0 + dy < height:
+                    out.append((x0 + dx, y0 + dy))
+    return np.asarray(out, np.int32)
+
+
+def assert_pixels_equal(oracle, frames, xy, gpu_accum, what, nthreads=16):
+    """Accumulates `frames` (a list of frame numbers) for the pixels xy with the CPU restatement and compares those
+    pixels of gpu_accum (H, W, 4) bit for bit."""
+    acc = np.zeros(gpu_accum.shape, np.float32)
+    for f in frames:
+        oracle.render_pixels(f, xy, acc, nthreads=nthreads)
+    cols, rows = xy[:, 0], xy[:, 1]
+    assert_bits_equal(acc[rows, cols, :3], gpu_accum[rows, cols, :3], what)
