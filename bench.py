@@ -12,6 +12,8 @@ resident on the GPU before the timed region.  With N > 1 the image tiles are int
 is N consecutive frames, so every rank keeps the work of one whole frame per step (weak scaling: its 1/N tile share
 of N frames, which the library renders as one merged pixel batch); --scaling strong keeps one frame per step
 instead, and whichever of the two is not the headline is timed as well and reported under "other_scaling".
+Before the timed loops rank 0 renders three whole frames of the same workload alone ("single_rank_same_workload"),
+so that the line carries its own one-GPU anchor at the resolution it was measured at.
 There is no collective inside a step's rendering; every step ends with the RCCL gather of the tile
 accumulators to rank 0.
 
@@ -32,6 +34,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth of the 8 XCDs
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # 256 CUs x 128 FP32 FMA lanes x 2 flops x 2.4 GHz
 
 
 def cpu_baseline(sc, nodes, seconds_target=15.0):
@@ -142,8 +145,33 @@ def main():
     rt.load_scene(sc, nodes)
     sharder = TileSharder(sc.width, sc.height, rank, world)
     accum = torch.zeros((sc.height, sc.width, 4), dtype=torch.float32, device=dev)
-    frame_buf = torch.zeros_like(accum) if args.balance == "dynamic" else None
+
+    # With several GPUs: what one rank alone needs for one frame of this same workload, measured by rank 0 before the
+    # timed loops while the others wait, so that the scaling efficiency can be read off this one line.
+    single_rank = None
+    if world > 1:
+        if rank == 0:
+            rt.set_accum_device(accum.data_ptr())
+            rt.set_tiles(0, 1, -1)
+            for f in (1, 2):
+                rt.render(f, 1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rays1 = 0
+            for f in (3, 4, 5):
+                rt.render(f, 1)
+                rays1 += rt.stats()["rays"]
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t0
+            single_rank = {"ms_per_frame": round(dt1 / 3 * 1e3, 3), "value": round(rays1 / dt1 / 1e6, 2), "unit": "Mrays/s",
+                           "note": "rank 0 alone, whole %dx%d frames, before the timed loops" % (sc.width, sc.height)}
+            accum.zero_()
+        dist.barrier()
+
+    # dynamic balancing: rank 0 renders into the accumulator, the others into a frame buffer that is empty between frames
+    frame_buf = torch.zeros_like(accum) if (args.balance == "dynamic" and rank != 0) else None
     rt.set_accum_device((frame_buf if frame_buf is not None else accum).data_ptr())
+    rt.clear_tile_log()
     if args.balance == "static":
         rt.set_tiles(*sharder.static_share())
     store = default_store() if (world > 1 and args.balance == "dynamic") else None
@@ -170,8 +198,6 @@ def main():
             take_stats()
             sharder.gather_static(accum)
         else:
-            frame_buf.zero_()
-            torch.cuda.current_stream().synchronize()
             if store is None:
                 rt.set_tiles(0, 1, -1)
                 rt.render(frame, 1)
@@ -181,7 +207,9 @@ def main():
                     rt.set_tiles(first, 1, count)
                     rt.render(frame, 1)
                     take_stats()
-            sharder.reduce_frame(frame_buf, accum)
+            tiles = rt.tile_log()
+            rt.clear_tile_log()
+            sharder.exchange_dynamic(tiles, frame_buf, accum)
 
     def sync():
         torch.cuda.synchronize()
@@ -265,7 +293,7 @@ def main():
                                    "max_recursion_depth %d, diffuse 1, specular 1" % (len(sc.tris), len(sc.textures), sc.width, sc.height, sc.max_depth),
                        "frames_per_step": frames_per_step,
                        "backend": "rccl" if backend == "nccl" else backend,
-                       "sharding": "tile-interleave x%d, %s" % (world, "gather to rank 0 per step" if args.balance == "static" else "dynamic batches + reduce per step")},
+                       "sharding": "tile-interleave x%d, %s" % (world, "gather to rank 0 per step" if args.balance == "static" else "dynamic batches from a shared counter + exchange of the rendered tiles per step")},
             "samples_per_s": round(samples / dt, 1),
             "rays_per_step": round(rays_total / args.steps),
             # rays of the last level that are worth zero hit or miss are counted in `value` (they are color() queries the
@@ -274,20 +302,27 @@ def main():
             "traversed_Mrays_per_s": round((rays_total - main_run["untraced"]) / dt / 1e6, 2),
             "gpu_kernel_ms_per_step": {"trace": round(trace_ms_sum / args.steps / world, 3), "shade_gather_accumulate": round(shade_ms_sum / args.steps / world, 3)},
         }
+        if single_rank is not None:
+            out["single_rank_same_workload"] = single_rank
         if other_run is not None:
             o = other_run
             out["other_scaling"] = {"scaling": "strong" if o["frames_per_step"] == 1 else "weak", "frames_per_step": o["frames_per_step"],
                                     "value": round(o["rays"] / o["dt"] / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(o["dt"] / args.steps * 1e3, 3),
                                     "ms_per_frame": round(o["dt"] / args.steps / o["frames_per_step"] * 1e3, 3)}
         if n_node is not None:
-            # Algorithmic bytes the traversal must move per ray: one 64-B record per node of the 4-wide tree it visits,
-            # one 64-B record per triangle whose quantised box it enters, 32 B ray in, 16 B hit out (a ray that is not
-            # traversed has only its direction read: 16 B less).  Launch duration: HIP events around every level's
-            # traversal on the scene's stream (rtx_stats.trace_ms / trace_launches), live, in the timed region.
+            # The traversal kernel's work per ray, from the kernels' own counters (one instrumented frame outside the
+            # timed region, identical rays): bytes = one 64-B record per node of the 4-wide tree it visits, one 64-B
+            # record per triangle whose quantised box it enters, 32 B ray in, 16 B hit out (a ray that is not traversed
+            # has only its direction read: 16 B less); flops = 22 per child-box test (6 subtract-multiplies, the interval
+            # folds and compares) + 70 per Triangle::hit (two 4-wide dots, the elimination with its divisions).
+            # Launch duration: HIP events around every level's traversal on the scene's stream
+            # (rtx_stats.trace_ms / trace_launches), live, in the timed region.
             launches = max(main_run["launches"], 1.0)
             avg_launch_ms = trace_ms_sum / launches
             bytes_per_ray = 64.0 * n_wide + 64.0 * n_leaf + 48.0 - 16.0 * main_run["untraced"] / max(rays_total, 1.0)
+            flops_per_ray = 22.0 * n_node + 70.0 * n_tri
             algo_gbs = bytes_per_ray * rays_total / (trace_ms_sum * 1e-3) / 1e9 if trace_ms_sum > 0 else 0.0  # per GPU: both sums run over the ranks
+            algo_tflops = flops_per_ray * rays_total / (trace_ms_sum * 1e-3) / 1e12 if trace_ms_sum > 0 else 0.0
             prof = offline_profile()
             pk = prof.get("k_trace_wide", {})
             rays_per_launch = rays_total / launches
@@ -295,24 +330,33 @@ def main():
             # the per-launch figures of the profile belong to the launches of the default single-GPU workload
             same_launches = world == 1 and (sc.width, sc.height, sc.max_depth) == (1920, 1080, 4)
             if not same_launches:
-                pk = {k: v for k, v in pk.items() if k in ("valu_frac", "valu_busy", "valu_busy_raw", "lane_util")}
+                pk = {k: v for k, v in pk.items() if k in ("lane_util", "issue_model_frac", "valu_class_share")}
             if "fetch_size_bytes_per_launch" in pk:
                 # FETCH_SIZE is 64 B x fabric read requests; a request for a random 64-byte record carries 64 B (measured
                 # factor 0.98), a streamed line 128 B (factor 2.0): the 32 B per ray of the queue read are added once more
                 traffic = round(pk["fetch_size_bytes_per_launch"] + pk["write_size_bytes_per_launch"] + 16.0 * rays_per_launch)
+            issued = pk["valu_insts_per_launch"] * 64.0 / rays_per_launch if "valu_insts_per_launch" in pk else None
             roof = {"kernel": "k_trace_wide",
-                    # neither of the two standard ceilings binds this kernel: its 25 MB of nodes and triangles are re-read from
-                    # L2 / Infinity Cache, and it has no matrix work; the counters show the vector ALUs saturated, so the
-                    # ceiling is vector-ALU lane-cycles and the figure is the share of them that does useful work
-                    "bound": "valu", "achieved": round(100.0 * pk["valu_frac"], 2) if "valu_frac" in pk else None, "peak": 100.0,
-                    "unit": "% of vector-ALU lane-cycles", "frac": pk.get("valu_frac"),
-                    "valu_busy": pk.get("valu_busy"), "valu_busy_raw": pk.get("valu_busy_raw"), "lane_util": pk.get("lane_util"),
-                    "valu_lane_slots_per_ray": round(pk["valu_insts_per_launch"] * 64.0 / rays_per_launch, 1) if "valu_insts_per_launch" in pk else None,
+                    # Work-normalised: the algorithmic flops of the launch over its duration against the FP32 vector peak
+                    # (256 CUs x 128 FMA lanes x 2 x 2.4 GHz).  The kernel has no matrix work, and its 25 MB of nodes and
+                    # triangles are re-read from L2 / Infinity Cache, so neither the MFMA nor the HBM ceiling is the one
+                    # it runs into: the vector ALUs' issue rate is (issue_model below).
+                    "bound": "valu", "achieved": round(algo_tflops, 2), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(algo_tflops / FP32_VECTOR_PEAK_TFLOPS, 4),
+                    "flops_per_ray": round(flops_per_ray, 1), "bytes_per_ray": round(bytes_per_ray, 1),
+                    "algorithmic_bytes": {"GBps": round(algo_gbs, 1), "frac_of_hbm_8000": round(algo_gbs / HBM_PEAK_GBS, 4),
+                                          "frac_of_l2_34500": round(algo_gbs / L2_PEAK_GBS, 4)},
+                    # what the vector ALUs issue against what the algorithm needs: lane-slots (64 x wave instructions) per ray
+                    "lane_slots_issued_per_ray": round(issued, 1) if issued else None,
+                    "lane_slots_issued_over_algorithmic": round(issued / flops_per_ray, 2) if issued else None,
+                    "lane_util": pk.get("lane_util"),
+                    # sum over instruction classes of (instructions / measured issue rate of the class) over the launch time:
+                    # 1.0 = the launch lasts exactly as long as the vector ALUs need to issue its instructions
+                    "issue_model": {"frac_of_launch": pk.get("issue_model_frac"), "model_ms_per_launch": pk.get("issue_model_ms_per_launch"),
+                                    "model_ms_bounds": pk.get("issue_model_ms_bounds"), "class_share": pk.get("valu_class_share")},
                     "counters_from": "%s @ %s (rocprofv3 passes of this command, raytracer_amd/tools/collect_profile.sh)" % (prof.get("source"), prof.get("commit")) if prof else None,
                     "traffic": traffic,
                     "traffic_GBps": round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1) if traffic else None,
-                    "algorithmic": {"bytes_per_ray": round(bytes_per_ray, 1), "GBps": round(algo_gbs, 1),
-                                    "frac_of_hbm_8000": round(algo_gbs / HBM_PEAK_GBS, 4), "frac_of_l2_34500": round(algo_gbs / L2_PEAK_GBS, 4)},
                     "avg_launch_ms": round(avg_launch_ms, 4),
                     "node_visits_per_ray": round(n_wide, 2), "leaf_fetches_per_ray": round(n_leaf, 3),
                     "box_tests_per_ray": round(n_node, 2), "triangle_tests_per_ray": round(n_tri, 3)}

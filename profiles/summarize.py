@@ -5,10 +5,12 @@ directory and into raytracer_amd/measured.json, the offline figures bench.py quo
 
 What is derived for the traversal kernel k_trace_wide (all template variants together):
   lane_util   = SQ_THREAD_CYCLES_VALU / (64 * SQ_INSTS_VALU): active lanes per vector-ALU instruction / 64
-  valu_busy   = 4 * SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 * SIMDs): SQ_ACTIVE_INST_VALU counts quad-cycles of
-                waves with a vector instruction in flight, GRBM_GUI_ACTIVE is summed over the 8 XCDs; the two come
-                from different runs, and an instruction that issues in 2 cycles still counts 4, so the quotient can
-                exceed 1: read it as "saturated" then
+  issue model = sum over instruction classes (sq3 pass: FP32 add / mul / fma, conversions, transcendentals counted by
+                the hardware, the rest split into fast and slow opcodes by the static mix of the walk step's code)
+                of instructions / issue rate of the class (tools/valu_rate at six waves per SIMD), over 1,024 SIMDs,
+                against the launch time of the kernel trace: 1.0 = the launch lasts as long as issuing takes
+  valu_busy_uncalibrated = 4 * SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 * SIMDs): kept for comparison with earlier
+                summaries; it is 4 x instructions / SIMD-cycles from two different runs, not a busy share
   fabric bytes: FETCH_SIZE and WRITE_SIZE are KiB.  FETCH_SIZE is 64 B x read requests of the L2 to the fabric
                 whatever a request carries; the calibration runs (tools/fetch_calib) give the factor per access
                 pattern: ~1.0 for random 64-byte records, 2.0 for random 128-byte records and for streams.
@@ -76,7 +78,7 @@ def main(src, dst):
                 short(r["Name"])[:44], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
             kt_ms[short(r["Name"])] = (float(r["TotalDurationNs"]) / 1e6, int(r["Calls"]))
     passes = {}
-    for sub, title in (("sq", "SQ counters"), ("sq2", "SQ instruction mix"), ("grbm", "GRBM (clock)"), ("fetch", "FETCH_SIZE"),
+    for sub, title in (("sq", "SQ counters"), ("sq3", "SQ vector instructions by class"), ("sq2", "SQ instruction mix"), ("grbm", "GRBM (clock)"), ("fetch", "FETCH_SIZE"),
                        ("write", "WRITE_SIZE"), ("cache", "cache counters")):
         agg, calls, _ = read_pass(src, sub)
         passes[sub] = (agg, calls)
@@ -152,15 +154,57 @@ def main(src, dst):
         if ng:
             cycles = gui / 8.0
             busy = 4.0 * act / (cycles * SIMDS)
-            rec["valu_busy_raw"] = round(busy, 3)
-            rec["valu_busy"] = round(min(1.0, busy), 3)
+            rec["valu_busy_uncalibrated"] = round(busy, 3)
             rec["waves_per_simd"] = round(4.0 * wavecyc / (cycles * SIMDS), 2)
-            out.append("   4 x SQ_ACTIVE_INST_VALU %.4g  /  (GRBM_GUI_ACTIVE / 8 = %.4g cycles x %d SIMDs)  ->  valu_busy %.3f%s; %.2f waves per SIMD resident" % (
-                4.0 * act, cycles, SIMDS, busy, " (>= 1: saturated)" if busy >= 1 else "", rec["waves_per_simd"]))
-            out.append("   useful share of the vector-ALU lane-cycles = min(1, valu_busy) x lane_util = %.3f" % (min(1.0, busy) * lane_util))
-            rec["valu_frac"] = round(min(1.0, busy) * lane_util, 4)
+            out.append("   4 x SQ_ACTIVE_INST_VALU %.4g  /  (GRBM_GUI_ACTIVE / 8 = %.4g cycles x %d SIMDs)  =  %.3f -- uncalibrated: the counter charges 4 cycles per instruction" % (
+                4.0 * act, cycles, SIMDS, busy))
+            out.append("      whatever it issues in and the two counters come from different runs, so this is 4 x instructions / SIMD-cycles, not a busy share; the issue-time model below is the")
+            out.append("      calibrated statement.  %.2f waves per SIMD resident" % rec["waves_per_simd"])
         if salu:
             out.append("   per vector instruction: %.3f scalar, %.4f vector-memory reads, %.4f LDS" % (salu / insts, vmem / insts, lds / insts))
+        # ---- issue-time model: the kernel's vector instructions by class (sq3 pass) over the issue rates measured by
+        # tools/valu_rate at six waves per SIMD (rates.log).  FP32 add / mul / fma and conversions are counted by the
+        # hardware; the rest (integer, compares, min/max, selects, moves) issues at the fast or the slow rate depending
+        # on the opcode, and is split by the share the walk step's code has of each (profiles/isa_table.py).
+        sq3, sq3c = passes.get("sq3", ({}, {}))
+        rates = {}
+        rp = os.path.join(src, "rates.log")
+        if os.path.exists(rp):
+            for line in open(rp):
+                if line.startswith("rate ") and "waves_per_simd 6" in line:
+                    name = line[5:26].strip()
+                    rates[name] = float(line.split("per_simd_instr_per_ns")[1])
+        tot3, n3 = family(sq3, sq3c, K, "SQ_INSTS_VALU")
+        if n3 and rates:
+            cls = {c: family(sq3, sq3c, K, "SQ_INSTS_VALU_" + c)[0] for c in ("ADD_F32", "MUL_F32", "FMA_F32", "CVT", "TRANS_F32", "INT32", "FLOPS_FP32")}
+            rest = tot3 - cls["ADD_F32"] - cls["MUL_F32"] - cls["FMA_F32"] - cls["CVT"] - cls["TRANS_F32"]
+            try:
+                sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+                import isa_table
+                _, static = isa_table.analyze()
+                fast_share = static["walk_other_fast_share"]
+            except Exception as e:     # no hipcc at hand: the figure of the committed table
+                static, fast_share = None, 0.28
+            r_fast = (rates.get("v_or_b32", 0.96) + rates.get("v_add_u32", 0.96) + rates.get("v_mov_b32", 1.0)) / 3.0
+            r_slow = sum(rates.get(k, 0.565) for k in ("v_max3_f32", "v_min_f32", "v_min_u32", "v_cmp_lt_f32 sgpr", "v_cndmask_b32 sgpr", "v_lshl_or_b32")) / 6.0
+            r_trans = 0.25 * r_fast * 1.16   # v_rcp_f32 and friends: a quarter of the full rate (not measured by the tool)
+            simd_ns = (cls["FMA_F32"] / rates.get("v_fma_f32", 0.776) + cls["MUL_F32"] / rates.get("v_mul_f32", 0.85) + cls["ADD_F32"] / rates.get("v_add_f32", 0.92) +
+                       cls["CVT"] / rates.get("v_cvt_f32_ubyte1", 0.577) + cls["TRANS_F32"] / r_trans + rest * (fast_share / r_fast + (1.0 - fast_share) / r_slow))
+            model_ms = simd_ns / SIMDS / n3 * 1e-6
+            lo_ms = (simd_ns - rest * (fast_share / r_fast + (1.0 - fast_share) / r_slow) + rest / r_fast) / SIMDS / n3 * 1e-6
+            hi_ms = (simd_ns - rest * (fast_share / r_fast + (1.0 - fast_share) / r_slow) + rest / r_slow) / SIMDS / n3 * 1e-6
+            rec["valu_class_share"] = {c: round(v / tot3, 4) for c, v in cls.items() if c != "FLOPS_FP32"}
+            rec["valu_class_share"]["other"] = round((rest - cls["INT32"]) / tot3, 4)
+            rec["hw_fp32_flops_per_launch"] = round(cls["FLOPS_FP32"] * 64.0 * lane_util / n3)   # the counter counts per wave instruction
+            rec["issue_model_ms_per_launch"] = round(model_ms, 4)
+            rec["issue_model_ms_bounds"] = [round(lo_ms, 4), round(hi_ms, 4)]
+            rec["issue_model_other_fast_share"] = fast_share
+            out.append("   vector instructions by class (sq3 pass, %d dispatches): " % n3 + ", ".join("%s %.1f %%" % (c, 100.0 * v / tot3) for c, v in cls.items() if c != "FLOPS_FP32") +
+                       ", other %.1f %%" % (100.0 * (rest - cls["INT32"]) / tot3))
+            out.append("   rates at six waves per SIMD (tools/valu_rate, wave-instructions per ns per SIMD): fma %.3f mul %.3f add %.3f cvt %.3f, fast integer/move %.3f, slow (min/max, compare, select, 3-operand) %.3f" % (
+                rates.get("v_fma_f32", 0), rates.get("v_mul_f32", 0), rates.get("v_add_f32", 0), rates.get("v_cvt_f32_ubyte1", 0), r_fast, r_slow))
+            out.append("   issue-time model: sum over classes of instructions / rate, over %d SIMDs = %.3f ms per launch (%.0f %% of the rest at the fast rate, as in the walk step's code;" % (SIMDS, model_ms, 100 * fast_share))
+            out.append("      all of it fast: %.3f ms, all of it slow: %.3f ms)" % (lo_ms, hi_ms))
         f, nf = family(fe, fec, K, "FETCH_SIZE")
         w, nw = family(wr, wrc, K, "WRITE_SIZE")
         if nf and nw:
@@ -173,6 +217,9 @@ def main(src, dst):
             cnt = sum(v[1] for k, v in kt_ms.items() if k.startswith(K) and not k.endswith("true>"))
             rec["kernel_trace_avg_launch_ms"] = round(tot / cnt, 4)
             out.append("   kernel trace: %d launches, %.3f ms in all, %.4f ms per launch" % (cnt, tot, tot / cnt))
+            if "issue_model_ms_per_launch" in rec:
+                rec["issue_model_frac"] = round(rec["issue_model_ms_per_launch"] / (tot / cnt), 4)
+                out.append("   issue-time model / measured launch time = %.3f: the share of the launch the vector ALUs need just to issue what the kernel executes" % rec["issue_model_frac"])
         measured[K] = rec
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "raytracer_amd", "measured.json")
     json.dump(measured, open(path, "w"), indent=1)

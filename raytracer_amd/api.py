@@ -64,6 +64,8 @@ HIP_SYMBOLS = {
     "rtx_scene_set_tonemap_table": (_i, [_vp, _vp, _vp, _i, C.c_uint8, C.c_uint8]),
     "rtx_tonemap_read": (_i, [_vp, _i, _vp]),
     "rtx_primary_hits": (_i, [_vp, _i, _ip, _fp]),
+    "rtx_host_alloc": (_vp, [C.c_size_t]),
+    "rtx_host_free": (_i, [_vp]),
     "rtx_trace_rays": (_i, [_vp, _i, _u32, _fp, _fp, _ip, _fp]),
     "rtx_trace_rays_noalloc": (_i, [_vp, _i, _u32, _vp, _vp, _vp, _vp]),
     "rtx_sample_radiance": (_i, [_vp, _u32, _fp]),
@@ -234,6 +236,8 @@ class RayTracer:
         self._tables_set = False
 
     def close(self):
+        for p, _ in self.__dict__.pop("_pinned_pool", {}).values():
+            self.lib.rtx_host_free(p)
         if getattr(self, "h", None):
             self.lib.rtx_scene_destroy(self.h)
             self.h = None
@@ -342,10 +346,29 @@ class RayTracer:
         assert accum.size == self.height * self.width * 4
         _chk(self.lib.rtx_accum_write(self.h, _p(accum.reshape(-1))))
 
-    def primary_hits(self, mode=0, want_tab=True):
+    def _pinned(self, name, dtype, count):
+        """A numpy array over page-locked memory from rtx_host_alloc, kept with the tracer and grown on demand."""
+        pool = self.__dict__.setdefault("_pinned_pool", {})
+        nbytes = int(count) * np.dtype(dtype).itemsize
+        if name not in pool or pool[name][1] < nbytes:
+            if name in pool:
+                self.lib.rtx_host_free(pool[name][0])
+            p = self.lib.rtx_host_alloc(nbytes)
+            if not p:
+                raise RtxError(-4, self.lib.rtx_last_error().decode())
+            pool[name] = (p, nbytes)
+        buf = (C.c_char * nbytes).from_address(pool[name][0])
+        return np.frombuffer(buf, dtype=dtype, count=count)
+
+    def primary_hits(self, mode=0, want_tab=True, pinned=False):
+        """pinned: the arrays returned are views of page-locked memory that the next pinned call overwrites."""
         n = self.height * self.width * 4
-        ids = np.zeros(n, np.int32)
-        tab = np.zeros((n, 3), np.float32) if want_tab else None
+        if pinned:
+            ids = self._pinned("ids", np.int32, n)
+            tab = self._pinned("tab", np.float32, n * 3).reshape(n, 3) if want_tab else None
+        else:
+            ids = np.zeros(n, np.int32)
+            tab = np.zeros((n, 3), np.float32) if want_tab else None
         _chk(self.lib.rtx_primary_hits(self.h, mode, ids.ctypes.data_as(_ip), _p(tab.reshape(-1)) if want_tab else None))
         return ids, tab
 

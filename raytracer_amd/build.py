@@ -75,18 +75,21 @@ def build_cli(force=False, verbose=False):
 
 
 def build_tools(force=False, verbose=False):
-    """tools/fetch_calib: the microbenchmark that calibrates rocprofv3's FETCH_SIZE (see tools/collect_profile.sh)."""
-    src = os.path.join(PKG, "tools", "fetch_calib.hip")
-    out = os.path.join(PKG, "tools", "fetch_calib")
-    if not os.path.exists(src):
-        return None
-    if not force and _newer(out, [src]):
-        return out
-    cmd = [_hipcc(), "-O2", "-std=c++17", "--offload-arch=gfx950", src, "-o", out]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return out
+    """tools/fetch_calib: the microbenchmark that calibrates rocprofv3's FETCH_SIZE; tools/valu_rate: the issue rates of
+    the vector instructions the traversal kernel uses (see tools/collect_profile.sh)."""
+    outs = []
+    for name in ("fetch_calib", "valu_rate"):
+        src = os.path.join(PKG, "tools", name + ".hip")
+        out = os.path.join(PKG, "tools", name)
+        if not os.path.exists(src):
+            continue
+        if force or not _newer(out, [src]):
+            cmd = [_hipcc(), "-O2", "-std=c++17", "--offload-arch=gfx950", src, "-o", out]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        outs.append(out)
+    return outs
 
 
 def build_all(force=False, verbose=False):

@@ -233,6 +233,8 @@ struct rtx_scene {
 	DevBuf<float4> dAccumOwn;
 	float4* dAccum = nullptr;  // own or external
 	bool texDirty = true;
+	DevBuf<int> dExportIds;     // rtx_primary_hits: triangle ids of the image's samples, kept from call to call
+	DevBuf<float> dExportTab;   // rtx_primary_hits: t, alpha, beta of the same samples
 	DevBuf<float4> dTilePack;   // tile exchange: this scene's share, packed (the share that is sent)
 	DevBuf<float4> dTileRecv;   // tile exchange, scene 0: the shares of the others as they arrive
 	DevBuf<int> dTileIds;       // tile exchange: the tile numbers of this scene's share (what k_pack_tiles walks over)
@@ -262,7 +264,7 @@ struct rtx_scene {
 		if (hNoallocFault) (void)hipHostFree(hNoallocFault);
 		if (hTileIds) (void)hipHostFree(hTileIds);
 		if (exchEvent) (void)hipEventDestroy(exchEvent);
-		dTileIds.release(); dTileIdsRecv.release();
+		dTileIds.release(); dTileIdsRecv.release(); dExportIds.release(); dExportTab.release();
 		for (auto& e : events) {
 			(void)hipEventDestroy(e.a);
 			(void)hipEventDestroy(e.b);
@@ -1569,28 +1571,18 @@ RTX_API int rtx_primary_hits(rtx_scene* s, int mode, int32_t* tri_ids, float* t_
 	rc = begin_call(s);
 	if (rc) return rc;
 	const size_t ns = (size_t)s->width * s->height * 4;
-	DevBuf<int> dIds;
-	DevBuf<float> dTab;
-	HIPCHK(dIds.alloc(ns));
-	hipError_t e = hipMemsetAsync(dIds.p, 0xFF, ns * sizeof(int), s->stream);
-	if (e == hipSuccess && t_alpha_beta) {
-		e = dTab.alloc(ns * 3);
-		if (e == hipSuccess) e = hipMemsetAsync(dTab.p, 0, ns * 3 * sizeof(float), s->stream);
-	}
-	if (e != hipSuccess) {
-		dIds.release();
-		dTab.release();
-		return fail(RTX_ERR_DEVICE, hipGetErrorString(e));
-	}
-	rc = render_batches(s, 0, 1, 2, mode, nullptr, dIds.p, t_alpha_beta ? dTab.p : nullptr);
-	if (rc == RTX_OK) {
-		e = hipMemcpy(tri_ids, dIds.p, ns * sizeof(int), hipMemcpyDeviceToHost);
-		if (e == hipSuccess && t_alpha_beta) e = hipMemcpy(t_alpha_beta, dTab.p, ns * 3 * sizeof(float), hipMemcpyDeviceToHost);
-		if (e != hipSuccess) rc = fail(RTX_ERR_DEVICE, hipGetErrorString(e));
-	}
-	dIds.release();
-	dTab.release();
+	// the export arrays stay with the scene: a call allocates only when the image has grown
+	if (s->dExportIds.n < ns) HIPCHK(s->dExportIds.alloc(ns));
+	if (t_alpha_beta && s->dExportTab.n < ns * 3) HIPCHK(s->dExportTab.alloc(ns * 3));
+	HIPCHK(hipMemsetAsync(s->dExportIds.p, 0xFF, ns * sizeof(int), s->stream));
+	if (t_alpha_beta) HIPCHK(hipMemsetAsync(s->dExportTab.p, 0, ns * 3 * sizeof(float), s->stream));
+	rc = render_batches(s, 0, 1, 2, mode, nullptr, s->dExportIds.p, t_alpha_beta ? s->dExportTab.p : nullptr);
 	if (rc) return rc;
+	// both arrays travel behind the kernels on the scene's stream, one wait for the two; into page-locked memory
+	// (rtx_host_alloc) they go at the speed of the link, into pageable memory the runtime stages them
+	HIPCHK(hipMemcpyAsync(tri_ids, s->dExportIds.p, ns * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+	if (t_alpha_beta) HIPCHK(hipMemcpyAsync(t_alpha_beta, s->dExportTab.p, ns * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+	HIPCHK(hipStreamSynchronize(s->stream));
 	// primary rays actually traced: pixels of this scene's tiles that lie inside the image
 	uint64_t px = 0;
 	const int tilesX = (s->width + TILE - 1) / TILE;
@@ -1601,6 +1593,21 @@ RTX_API int rtx_primary_hits(rtx_scene* s, int mode, int32_t* tri_ids, float* t_
 	}
 	s->stats.rays = s->stats.rays_per_level[0] = px * 4;
 	return finish_stats(s);
+}
+
+RTX_API void* rtx_host_alloc(size_t bytes) {
+	void* p = nullptr;
+	if (hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		fail(RTX_ERR_MEMORY, "cannot allocate " + std::to_string(bytes) + " bytes of page-locked host memory");
+		return nullptr;
+	}
+	return p;
+}
+
+RTX_API int rtx_host_free(void* p) {
+	if (p) HIPCHK(hipHostFree(p));
+	return RTX_OK;
 }
 
 RTX_API int rtx_trace_rays(rtx_scene* s, int mode, uint32_t n, const float* origins, const float* directions,

@@ -262,6 +262,22 @@ def test_bunny_class_1080p_culled_equals_exhaustive(libs):
     win = ids0.reshape(1080, 1920, 4)[y0:y0 + 36, x0:x0 + 64].reshape(-1)
     assert np.array_equal(ids_o, win)
     assert s0["rays"] == 1920 * 1080 * 4
+    # the same call into page-locked arrays (rtx_host_alloc): identical answers; its wall time, read-back included, is
+    # printed (run pytest with -s) and loosely bounded -- the kernels take about 1 ms, 133 MB cross the link
+    import time
+    ids_p, tab_p = rt.primary_hits(0, pinned=True)
+    assert np.array_equal(ids_p, ids0) and np.array_equal(bits(tab_p), bits(tab0))
+    t_all, t_ids = [], []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        rt.primary_hits(0, pinned=True)
+        t_all.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        rt.primary_hits(0, want_tab=False, pinned=True)
+        t_ids.append(time.perf_counter() - t0)
+    print("rtx_primary_hits 1920x1080, page-locked arrays: ids + t/alpha/beta %.2f ms, ids only %.2f ms (kernels %.2f ms)" % (
+        min(t_all) * 1e3, min(t_ids) * 1e3, rt.stats()["trace_ms"] + rt.stats()["shade_ms"]))
+    assert min(t_all) < 0.012 and min(t_ids) < 0.006
 
 
 def test_atrium_tiles_arena_and_determinism(libs):
