@@ -97,7 +97,8 @@ def analyze():
         if m and not ln.strip().startswith(";") and not ln.strip().startswith("."):
             ins.append((m.group(1), m.group(2)))
     # anchors
-    node = next(i for i in range(len(ins) - 3) if all(ins[i + k][0] == "global_load_dwordx4" for k in range(4)) and "offset:48" in ins[i][1])
+    # the node fetch: four 16-byte loads off one base, offsets 48, 32, 16, 0 (a scheduling s_nop may sit among them)
+    node = next(i for i, (op, a) in enumerate(ins) if op == "global_load_dwordx4" and "offset:48" in a)
     first_ray = next(i for i, (op, a) in enumerate(ins) if op == "global_load_dwordx4")
     bperm = next(i for i, (op, a) in enumerate(ins) if op == "ds_write_b8")   # the helper table of the leaf phase
     # the walk step starts a few instructions before the fetch (address arithmetic): back to the last branch

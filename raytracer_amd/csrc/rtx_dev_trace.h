@@ -405,9 +405,18 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 	// chunks of the full size a queue of a million rays would occupy two waves in three and the launch would
 	// last as long as one wave needs for its whole chunk.
 	chunk = min(chunk, max(64, (int)((unsigned)n / (gridDim.x * (TRACE_THREADS / 64) * 3u) + 63u) & ~63));
-	__shared__ int stk[STACK][TRACE_THREADS];
+	// The per-lane stack lives in LDS, one row of the array per entry; a lane's stack pointer is kept as the LDS address
+	// of its top entry (`top`), so that a push or a pop is one LDS instruction with a constant offset and no address
+	// arithmetic of its own.  Row 0 is never written: `top` points there while the stack is empty.
+	__shared__ int stk[STACK + 1][TRACE_THREADS];
 	__shared__ unsigned char sPool[TRACE_THREADS / 64][128];  // leaf phase: lanes that want help | lanes that help, by rank
 	const int tid = threadIdx.x;
+	typedef __attribute__((address_space(3))) int lds_int;
+	constexpr int ROW = TRACE_THREADS;                          // ints from one stack entry of a lane to the next
+	lds_int* const stkEmpty = (lds_int*)&stk[0][tid];           // `top` of an empty stack
+	lds_int* const stkLast = (lds_int*)&stk[STACK][tid];        // the last entry there is room for
+	lds_int* const stkLimit = stkLast + ROW;                    // a node whose entered children would reach beyond this does not fit
+	lds_int* top = stkEmpty;
 	const unsigned lane = (unsigned)tid & 63u;
 	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
 	unsigned boxTests = 0, triTests = 0, nodeVisits = 0, leafFetches = 0;
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 	unsigned myVisits = 0, maxVisits = 0, over100 = 0, over300 = 0;
 	int cnext = 0, cend = 0;
 	bool more = true, firstChunk = true;
-	int j = -1, cur = -1, sp = 0;
+	int j = -1, cur = -1;
 	RaySlab r;
 	r.ox = r.oy = r.oz = r.ix = r.iy = r.iz = r.mx = r.my = r.mz = 0.0f;
 	r.nx = r.ny = r.nz = false;
@@ -508,7 +517,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 							r.mx = eps * fabsf(wix); r.my = eps * fabsf(wiy); r.mz = eps * fabsf(wiz);
 							best.t = FLT_MAX; best.alpha = 0.0f; best.beta = 0.0f; best.rank = 0x7FFFFFFF;
 							found = false;
-							sp = 0;
+							top = stkEmpty;
 							cur = 0;
 							pend0 = pend1 = -1;
 							busy = true;
@@ -526,7 +535,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 		// A wave that has found the queue exhausted and is down to a few rays hands those to the wave-per-ray kernel: they
 		// are its longest, and one lane each would walk them one node after the other while the launch waits.
 		if (!more && 64 - nidle <= tailLanes) visitsLeft = 0;
-		const bool canWalk = busy && pend1 < 0 && (cur >= 0 || sp > 0);
+		const bool canWalk = busy && pend1 < 0 && (cur >= 0 || top != stkEmpty);
 		const unsigned long long mWalk = __builtin_amdgcn_ballot_w64(canWalk);
 		const unsigned long long mLeaf = __builtin_amdgcn_ballot_w64(busy && pend0 >= 0);
 		if (mWalk == 0ull && mLeaf == 0ull) {
@@ -549,7 +558,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 				walkLanes += __popcll(mWalk);
 				walkIdle += __popcll(__builtin_amdgcn_ballot_w64(!busy));
 				walkParked += __popcll(__builtin_amdgcn_ballot_w64(busy && pend1 >= 0));
-				walkLeafWait += __popcll(__builtin_amdgcn_ballot_w64(busy && pend1 < 0 && cur < 0 && sp == 0));
+				walkLeafWait += __popcll(__builtin_amdgcn_ballot_w64(busy && pend1 < 0 && cur < 0 && top == stkEmpty));
 			}
 		}
 		if (leafPhase) {
@@ -557,9 +566,9 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 			// tested on its own, exact box, exact slab predicate, exact triangle test; one leaf per lane and pass.
 #ifdef RTX_BOUNDS_CHECK
 			if (busy && pend0 >= 0 && (unsigned)((pend0 >> 1) + (pend0 & 1)) >= (unsigned)sc.nTris) {
-				printf("[rtx] k_trace_wide: leaf record %d (+%d) of %d (ray %d, sp %d, cur %d, pend1 %d)\n", pend0 >> 1, pend0 & 1, sc.nTris, j, sp, cur, pend1);
+				printf("[rtx] k_trace_wide: leaf record %d (+%d) of %d (ray %d, sp %d, cur %d, pend1 %d)\n", pend0 >> 1, pend0 & 1, sc.nTris, j, (int)(top - stkEmpty) / ROW, cur, pend1);
 				atomicOr(sc.fault, FAULT_LEAF);
-				pend0 = pend1 = -1; cur = -1; sp = 0;
+				pend0 = pend1 = -1; cur = -1; top = stkEmpty;
 			}
 #endif
 			// The second triangle of a leaf is tested at the same time as the first, by a lane that has no leaf of its own
@@ -638,7 +647,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 				unsafeList[atomicAdd(unsafeCount, 1u)] = j;
 				busy = false;
 				cur = -1;
-				sp = 0;
+				top = stkEmpty;
 				pend0 = pend1 = -1;
 			}
 			if (busy && pend0 >= 0) {
@@ -647,7 +656,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 				if (ANYHIT && found) {
 					pend0 = -1;
 					cur = -1;
-					sp = 0;
+					top = stkEmpty;
 				}
 			}
 		}
@@ -655,24 +664,29 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 			int item = 0;  // what this lane looks at next: > 0 node, < 0 ~rank of a leaf, 0 nothing yet
 #ifdef RTX_BOUNDS_CHECK
 			if (cur >= sc.nWide) {
-				printf("[rtx] k_trace_wide: node %d of %d (ray %d, sp %d, pend %d %d)\n", cur, sc.nWide, j, sp, pend0, pend1);
+				printf("[rtx] k_trace_wide: node %d of %d (ray %d, sp %d, pend %d %d)\n", cur, sc.nWide, j, (int)(top - stkEmpty) / ROW, pend0, pend1);
 				atomicOr(sc.fault, FAULT_NODE);
-				cur = -1; sp = 0;
+				cur = -1; top = stkEmpty;
 			}
-			if (sp < 0 || sp > STACK) {
-				printf("[rtx] k_trace_wide: stack pointer %d (ray %d)\n", sp, j);
+			if (top < stkEmpty || top > stkLast || (int)(top - stkEmpty) % ROW != 0) {
+				printf("[rtx] k_trace_wide: stack pointer %d (ray %d)\n", (int)(top - stkEmpty), j);
 				atomicOr(sc.fault, FAULT_STACK);
-				sp = 0;
+				top = stkEmpty;
 			}
 #endif
-			if (cur >= 0 && --visitsLeft < 0) {
-				// A launch lasts as long as its longest ray, and one lane walks one node after the other.  A ray
-				// that has used up its allowance starts over in k_trace_long, where a whole wave works on it.
-				longList[atomicAdd(longCount, 1u)] = j;
-				busy = false;
-				cur = -1;
-				sp = 0;
-				pend0 = -1;
+			// A launch lasts as long as its longest ray, and one lane walks one node after the other.  A ray
+			// that has used up its allowance starts over in k_trace_long, where a whole wave works on it.  (Rare: the
+			// wave asks once whether any of its lanes is there, so that the step of the others does not run through the
+			// hand-over's branches.)
+			if (cur >= 0) --visitsLeft;
+			if (__builtin_amdgcn_ballot_w64(visitsLeft < 0) != 0ull) {
+				if (cur >= 0 && visitsLeft < 0) {
+					longList[atomicAdd(longCount, 1u)] = j;
+					busy = false;
+					cur = -1;
+					top = stkEmpty;
+					pend0 = -1;
+				}
 			}
 			if (cur >= 0) {
 				const float4* W = sc.wide + (size_t)cur * 4;
@@ -724,35 +738,42 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 				RTX_CSWAP(1, 3)
 				RTX_CSWAP(1, 2)
 #undef RTX_CSWAP
-				// the nearest is looked at next, the others wait with the farthest at the bottom
-				if (sp + nh - 1 > STACK) {
-					// no room: the ray starts over in the binary-tree kernel, whose stack covers its whole tree
-					unsafeList[atomicAdd(unsafeCount, 1u)] = j;
-					if (STATS) overflows++;
-					busy = false;
-					sp = 0;
-					nh = 0;
-					pend0 = -1;
+				// the nearest is looked at next, the others wait with the farthest at the bottom: entry k of the sorted four
+				// (k = 1, 2, 3) goes nh - k rows above the present top
+				lds_int* above = top + nh * ROW;
+				if (__builtin_amdgcn_ballot_w64(above > stkLimit) != 0ull) {
+					if (above > stkLimit) {
+						// no room: the ray starts over in the binary-tree kernel, whose stack covers its whole tree
+						unsafeList[atomicAdd(unsafeCount, 1u)] = j;
+						if (STATS) overflows++;
+						busy = false;
+						top = stkEmpty;
+						above = stkEmpty;
+						nh = 0;
+						pend0 = -1;
+					}
 				}
-				if (nh > 3) stk[sp][tid] = cd[3];
-				if (nh > 2) stk[sp + nh - 3][tid] = cd[2];
-				if (nh > 1) stk[sp + nh - 2][tid] = cd[1];
-				sp += max(nh - 1, 0);
-				item = nh > 0 ? cd[0] : 0;
+				if (nh > 3) top[ROW] = cd[3];
+				if (nh > 2) above[-2 * ROW] = cd[2];
+				if (nh > 1) above[-ROW] = cd[1];
+				if (nh > 0) {
+					top = above - ROW;
+					item = cd[0];
+				}
 				cur = -1;
 			}
-			if (item == 0 && sp > 0) {
-				sp--;
-				item = stk[sp][tid];
+			if (item == 0 && top != stkEmpty) {
+				item = *top;
+				top -= ROW;
 			}
 			if (item < 0) {
 				// a leaf: keep it and look at what comes after it
 				if (pend0 < 0) pend0 = ~item;
 				else pend1 = ~item;
 				item = 0;
-				if (pend1 < 0 && sp > 0) {
-					sp--;
-					item = stk[sp][tid];
+				if (pend1 < 0 && top != stkEmpty) {
+					item = *top;
+					top -= ROW;
 					if (item < 0) {
 						pend1 = ~item;
 						item = 0;
@@ -761,7 +782,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 			}
 			if (item > 0) cur = item;
 		}
-		if (busy && cur < 0 && pend0 < 0 && sp == 0) {
+		if (busy && cur < 0 && pend0 < 0 && top == stkEmpty) {
 			int id = found ? (ANYHIT ? 0 : best.rank) : -1;
 			put_hit<ANYHIT>(hits, j, id, best.t, best.alpha, best.beta);
 			busy = false;
