@@ -497,6 +497,47 @@ def test_trees_the_wide_kernel_cannot_use_and_short_stacks(libs, monkeypatch):
     assert short.stats()["rays_set_aside"] >= ref.stats()["rays_set_aside"]
 
 
+@pytest.mark.parametrize("stack", ["24", "16"])
+def test_nodes_smaller_than_the_culling_slack(libs, monkeypatch, stack):
+    """The quantised child boxes are tested inflated by a slack of 2^-14 of the largest coordinate in play.  A scene a
+    hundred times smaller than usual and 8,000 units from the origin has nodes narrower than that slack: the empty
+    interval that stands for an absent child then opens up, absent children count as entered, a node can ask for more
+    stack than the host's bound foresees, and the ray is set aside for the binary-tree kernel at run time (with the
+    16-entry stack all the more).  Primary hits, per-sample radiance and the accumulator must still equal the CPU
+    restatement bit for bit, in both traversal modes."""
+    monkeypatch.setenv("RTX_WIDE_STACK", stack)
+    sc = scenes.mixed_scene(seed=8, width=72, height=48, max_depth=3, n_diff=2, n_spec=1, with_sky=True)
+    off = np.array([8000.0, 8000.0, 8000.0], np.float32)
+    k = np.float32(0.01)
+    sc.tris = sc.tris.copy()
+    sc.tris["v"][:, :, :3] = sc.tris["v"][:, :, :3] * k + off
+    sc.eye = tuple((np.asarray(sc.eye, np.float32) * k + off).tolist())
+    sc.at = tuple((np.asarray(sc.at, np.float32) * k + off).tolist())
+    O = load_into(binding.Oracle(), sc)
+    rt = gpu_scene(sc)
+    ids_o, tab_o = O.primary_hits()
+    assert 0.3 < (ids_o >= 0).mean()
+    for mode in (0, 1):
+        ids_g, tab_g = rt.primary_hits(mode)
+        assert np.array_equal(ids_o, ids_g), "mode %d: %d ids differ" % (mode, (ids_o != ids_g).sum())
+        assert_bits_equal(tab_o[ids_o >= 0], tab_g[ids_o >= 0], "t/alpha/beta mode %d" % mode)
+    assert_bits_equal(O.sample_radiance(1, 0, 0, sc.width, sc.height)[..., :3], rt.sample_radiance(1)[..., :3], "per-sample radiance")
+    acc_o = np.zeros((sc.height, sc.width, 4), np.float32)
+    O.reset_counts()
+    for f in (1, 2):
+        O.render_rows(f, acc_o, nthreads=8)
+    rt.reset()
+    rt.set_instrumented(True)
+    rt.render(1, 2)
+    st = rt.stats()
+    assert_bits_equal(acc_o[..., :3], rt.accum()[..., :3], "accumulator")
+    assert st["rays"] == O.ray_count()
+    # the slack really is wider than the nodes: far more box tests pass than in the same scene at its usual place
+    assert st["node_tests"] / st["rays"] > 100, st["node_tests"] / st["rays"]
+    if stack == "16":
+        assert st["rays_set_aside"] > 0
+
+
 def test_leaves_of_two_triangles_change_nothing(libs, monkeypatch):
     """The traversal tree keeps the two halves of a quad (triangles that share an edge and, nearly, a box) in one
     leaf; each triangle is still tested on its own, so ids, t/alpha/beta, radiance and ray counts must equal those of
