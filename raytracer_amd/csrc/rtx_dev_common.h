@@ -16,7 +16,10 @@ constexpr int TILE = 64;            // image tile edge in pixels (sharding granu
 constexpr int BLK = 4;              // a wave covers a BLK x BLK pixel block x 4 sub-samples
 constexpr int BLOCKS_PER_TILE = (TILE / BLK) * (TILE / BLK);
 constexpr int SAMPLES_PER_BLOCK = BLK * BLK * 4;  // 64 = one wave
-constexpr int TRACE_THREADS = 256;
+#ifndef RTX_TRACE_THREADS
+#define RTX_TRACE_THREADS 256
+#endif
+constexpr int TRACE_THREADS = RTX_TRACE_THREADS;  // threads per block of the traversal kernels (experiments: -DRTX_TRACE_THREADS=64 or 128)
 // Counter block of a recursion level (unsigned words, zeroed at the start of a pixel batch): 0 queue length,
 // 1 dead slots, 2 shaded hits, 3 texel fetches, 4 overflow flag, 5-9 cursors and list lengths of the traversal.
 constexpr int CNT_STRIDE = 16;

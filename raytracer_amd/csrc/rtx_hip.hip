@@ -235,6 +235,9 @@ struct rtx_scene {
 	bool texDirty = true;
 	DevBuf<int> dExportIds;     // rtx_primary_hits: triangle ids of the image's samples, kept from call to call
 	DevBuf<float> dExportTab;   // rtx_primary_hits: t, alpha, beta of the same samples
+	DevBuf<float4> dExportRad;  // rtx_sample_radiance: per-sample radiance of the image
+	DevBuf<float4> dRaysO, dRaysD, dRaysH;  // rtx_trace_rays: ray and hit records, kept from call to call
+	DevBuf<int> dRaysList;                  // ... and the two ray lists of the traversal
 	DevBuf<float4> dTilePack;   // tile exchange: this scene's share, packed (the share that is sent)
 	DevBuf<float4> dTileRecv;   // tile exchange, scene 0: the shares of the others as they arrive
 	DevBuf<int> dTileIds;       // tile exchange: the tile numbers of this scene's share (what k_pack_tiles walks over)
@@ -264,7 +267,7 @@ struct rtx_scene {
 		if (hNoallocFault) (void)hipHostFree(hNoallocFault);
 		if (hTileIds) (void)hipHostFree(hTileIds);
 		if (exchEvent) (void)hipEventDestroy(exchEvent);
-		dTileIds.release(); dTileIdsRecv.release(); dExportIds.release(); dExportTab.release();
+		dTileIds.release(); dTileIdsRecv.release(); dExportIds.release(); dExportTab.release(); dExportRad.release(); dRaysO.release(); dRaysD.release(); dRaysH.release(); dRaysList.release();
 		for (auto& e : events) {
 			(void)hipEventDestroy(e.a);
 			(void)hipEventDestroy(e.b);
@@ -1625,34 +1628,37 @@ RTX_API int rtx_trace_rays(rtx_scene* s, int mode, uint32_t n, const float* orig
 		ho[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 0.0f);
 		hd[i] = make_float4(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2], 0.0f);
 	}
-	DevBuf<float4> dO, dD, dH;
-	DevBuf<int> dIds, dList;
-	DevBuf<float> dTab;
-	hipError_t e = dO.alloc(n);
-	if (e == hipSuccess) e = dList.alloc((size_t)n * 2);
-	if (e == hipSuccess) e = dD.alloc(n);
-	if (e == hipSuccess) e = dH.alloc(n);
-	if (e == hipSuccess) e = dIds.alloc(n);
-	if (e == hipSuccess) e = dTab.alloc((size_t)n * 3);
-	if (e == hipSuccess) e = hipMemcpy(dO.p, ho.data(), (size_t)n * 16, hipMemcpyHostToDevice);
-	if (e == hipSuccess) e = hipMemcpy(dD.p, hd.data(), (size_t)n * 16, hipMemcpyHostToDevice);
+	// device arrays stay with the scene and grow on demand; ids and t/alpha/beta share the export arrays of rtx_primary_hits
+	hipError_t e = hipSuccess;
+	if (s->dRaysO.n < n) e = s->dRaysO.alloc(n);
+	if (e == hipSuccess && s->dRaysD.n < n) e = s->dRaysD.alloc(n);
+	if (e == hipSuccess && s->dRaysH.n < n) e = s->dRaysH.alloc(n);
+	if (e == hipSuccess && s->dRaysList.n < (size_t)n * 2) e = s->dRaysList.alloc((size_t)n * 2);
+	if (e == hipSuccess && s->dExportIds.n < n) e = s->dExportIds.alloc(n);
+	if (e == hipSuccess && s->dExportTab.n < (size_t)n * 3) e = s->dExportTab.alloc((size_t)n * 3);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		return fail(RTX_ERR_MEMORY, std::string("rtx_trace_rays: ") + hipGetErrorString(e));
+	}
+	e = hipMemcpy(s->dRaysO.p, ho.data(), (size_t)n * 16, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(s->dRaysD.p, hd.data(), (size_t)n * 16, hipMemcpyHostToDevice);
 	if (e == hipSuccess) {
 		const DevScene d = make_dev_scene(s);
 		e = hipMemsetAsync(s->dCounts.p, 0, CNT_STRIDE * sizeof(unsigned), s->stream);
 		if (e == hipSuccess) e = hipMemsetAsync(s->dCounts.p + FAULT_WORD, 0, sizeof(unsigned), s->stream);
-		if (e == hipSuccess) rc = launch_trace(s, d, false, mode == 1, dO.p, dD.p, dH.p, (int)n, s->dCounts.p, dList.p);
-		if (rc == RTX_OK) {
-			hipLaunchKernelGGL(k_export_hits_linear, dim3((n + 255) / 256), dim3(256), 0, s->stream, d, (int)n, dH.p, dIds.p, dTab.p);
+		if (e == hipSuccess) rc = launch_trace(s, d, false, mode == 1, s->dRaysO.p, s->dRaysD.p, s->dRaysH.p, (int)n, s->dCounts.p, s->dRaysList.p);
+		if (e == hipSuccess && rc == RTX_OK) {
+			hipLaunchKernelGGL(k_export_hits_linear, dim3((n + 255) / 256), dim3(256), 0, s->stream, d, (int)n, s->dRaysH.p, s->dExportIds.p, s->dExportTab.p);
 			e = hipGetLastError();
 			if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
 			if (e == hipSuccess) e = hipMemcpy(s->hCounts + FAULT_WORD, s->dCounts.p + FAULT_WORD, sizeof(unsigned), hipMemcpyDeviceToHost);
 			if (e == hipSuccess) e = hipMemcpy(s->hCounts + UNSAFE_SLOT, s->dCounts.p + UNSAFE_SLOT, sizeof(unsigned), hipMemcpyDeviceToHost);
 			if (e == hipSuccess) rc = check_fault(s->hCounts[FAULT_WORD]);
-			if (e == hipSuccess) e = hipMemcpy(tri_ids, dIds.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
-			if (e == hipSuccess && t_alpha_beta) e = hipMemcpy(t_alpha_beta, dTab.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost);
+			if (e == hipSuccess) e = hipMemcpy(tri_ids, s->dExportIds.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+			if (e == hipSuccess && t_alpha_beta) e = hipMemcpy(t_alpha_beta, s->dExportTab.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost);
 		}
 	}
-	dO.release(); dD.release(); dH.release(); dIds.release(); dTab.release(); dList.release();
+	if (e != hipSuccess || rc) (void)hipStreamSynchronize(s->stream);  // nothing of a failed call stays in flight over the scene's arrays
 	if (e != hipSuccess) return fail(RTX_ERR_DEVICE, hipGetErrorString(e));
 	if (rc) return rc;
 	rc = harvest_events(s);
@@ -1720,20 +1726,11 @@ RTX_API int rtx_sample_radiance(rtx_scene* s, uint32_t frame, float* host_out) {
 	rc = begin_call(s);
 	if (rc) return rc;
 	const size_t ns = (size_t)s->width * s->height * 4;
-	DevBuf<float4> dOut;
-	HIPCHK(dOut.alloc(ns));
-	hipError_t e = hipMemcpy(dOut.p, host_out, ns * sizeof(float4), hipMemcpyHostToDevice);
-	if (e != hipSuccess) {
-		dOut.release();
-		return fail(RTX_ERR_DEVICE, hipGetErrorString(e));
-	}
-	rc = render_batches(s, frame, 1, 1, 0, dOut.p, nullptr, nullptr);
-	if (rc == RTX_OK) {
-		e = hipMemcpy(host_out, dOut.p, ns * sizeof(float4), hipMemcpyDeviceToHost);
-		if (e != hipSuccess) rc = fail(RTX_ERR_DEVICE, hipGetErrorString(e));
-	}
-	dOut.release();
+	if (s->dExportRad.n < ns) HIPCHK(s->dExportRad.alloc(ns));
+	HIPCHK(hipMemcpy(s->dExportRad.p, host_out, ns * sizeof(float4), hipMemcpyHostToDevice));
+	rc = render_batches(s, frame, 1, 1, 0, s->dExportRad.p, nullptr, nullptr);
 	if (rc) return rc;
+	HIPCHK(hipMemcpy(host_out, s->dExportRad.p, ns * sizeof(float4), hipMemcpyDeviceToHost));
 	return finish_stats(s);
 }
 
