@@ -89,23 +89,27 @@ __device__ __forceinline__ float clamp01(float u) {
 	return u;
 }
 
-// Texture::sampleTexture (src/Texture.cpp:41-53) with clamped coordinates and the
-// powf(c/255, 2.2) decode taken from the host-computed table.
-__device__ __forceinline__ float3 tex_fetch(const DevScene& sc, int id, float u, float v) {
-	int4 d = sc.texDesc[id];
-	u = clamp01(u);
-	v = clamp01(v);
-	float uMax = (float)(d.y - 1);
-	float vMax = (float)(d.z - 1);
-	int sx = (int)roundf(u * uMax);
-	int sy = (int)roundf(v * vMax);
-	const uint8_t* c = sc.texels + (size_t)(uint32_t)d.x + ((size_t)sy * (size_t)d.y + (size_t)sx) * 3;
-	return make_float3(sc.gammaT[c[0]], sc.gammaT[c[1]], sc.gammaT[c[2]]);
+// Small read-only tables a block keeps in LDS: the 256-entry texel decode (powf(c/255, 2.2)) and the descriptors of
+// the first LDS_TEX textures.  Every look-up in them is a scattered access of a whole wave; in LDS it costs no trip to
+// the vector-memory path, which the shading kernels are bound by.
+constexpr int LDS_TEX = 64;
+struct LdsTables {
+	const float* gamma;   // 256 floats
+	const int4* desc;     // LDS_TEX descriptors: those of the first min(nTex, LDS_TEX) textures, then the six sky faces' at LDS_SKY
+};
+constexpr int LDS_SKY = LDS_TEX;  // desc[LDS_SKY + face]: the descriptor of a sky face, without the detour over its texture id
+// Fills the block's tables (every thread of the block calls it; ends with a barrier).  desc: LDS_TEX + 6 entries.
+__device__ __forceinline__ void lds_tables_fill(const DevScene& sc, float* gamma, int4* desc, int nThreads) {
+	for (int i = threadIdx.x; i < 256; i += nThreads) gamma[i] = sc.gammaT[i];
+	for (int i = threadIdx.x; i < min(sc.nTex, LDS_TEX); i += nThreads) desc[i] = sc.texDesc[i];
+	if (threadIdx.x < 6) desc[LDS_SKY + threadIdx.x] = sc.hasSky ? sc.texDesc[sc.skyTex[threadIdx.x]] : make_int4(0, 1, 1, 0);
+	__syncthreads();
 }
 
-// The same texel as raw bytes (r | g << 8 | b << 16): whoever needs the colour looks the bytes up in gammaT.
-__device__ __forceinline__ unsigned tex_fetch_rgb(const DevScene& sc, int id, float u, float v) {
-	int4 d = sc.texDesc[id];
+// The texel as raw bytes (r | g << 8 | b << 16).  The three bytes are taken with one four-byte load at the texel's
+// (unaligned) address -- global memory takes unaligned loads, and one scattered load per lane costs a third of three;
+// the texel blob is padded so that the fourth byte of its last texel exists.
+__device__ __forceinline__ unsigned texel_rgb(const DevScene& sc, int4 d, float u, float v) {
 	u = clamp01(u);
 	v = clamp01(v);
 	float uMax = (float)(d.y - 1);
@@ -113,7 +117,26 @@ __device__ __forceinline__ unsigned tex_fetch_rgb(const DevScene& sc, int id, fl
 	int sx = (int)roundf(u * uMax);
 	int sy = (int)roundf(v * vMax);
 	const uint8_t* c = sc.texels + (size_t)(uint32_t)d.x + ((size_t)sy * (size_t)d.y + (size_t)sx) * 3;
-	return (unsigned)c[0] | ((unsigned)c[1] << 8) | ((unsigned)c[2] << 16);
+	unsigned w;
+	__builtin_memcpy(&w, c, 4);
+	return w & 0x00FFFFFFu;
+}
+__device__ __forceinline__ unsigned tex_fetch_rgb(const DevScene& sc, const LdsTables& lt, int id, float u, float v) {
+	int4 d = lt.desc[min(id, LDS_TEX - 1)];
+	if (id >= LDS_TEX) {
+		// a scene with more textures than the table holds: the descriptor comes from global memory (the empty asm keeps
+		// the two look-ups apart: merged, they become one slow load through an address of either kind)
+		d = sc.texDesc[id];
+		asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z));
+	}
+	return texel_rgb(sc, d, u, v);
+}
+
+// Texture::sampleTexture (src/Texture.cpp:41-53) with clamped coordinates and the
+// powf(c/255, 2.2) decode taken from the host-computed table.
+__device__ __forceinline__ float3 tex_fetch(const DevScene& sc, const LdsTables& lt, int id, float u, float v) {
+	const unsigned rgb = tex_fetch_rgb(sc, lt, id, u, v);
+	return make_float3(lt.gamma[rgb & 0xFFu], lt.gamma[(rgb >> 8) & 0xFFu], lt.gamma[rgb >> 16]);
 }
 
 // Face selection of Skybox::sampleBackground (src/Skybox.cpp:32-84): the first of front, back, left, right, top,
@@ -169,11 +192,12 @@ __device__ __forceinline__ int sky_face(float dx, float dy, float dz, float& u, 
 }
 
 // Skybox::sampleBackground (src/Skybox.cpp:32-84).
-__device__ float3 sky_fetch(const DevScene& sc, float dx, float dy, float dz) {
+__device__ __forceinline__ float3 sky_fetch(const DevScene& sc, const LdsTables& lt, float dx, float dy, float dz) {
 	float u, v;
 	const int face = sky_face(dx, dy, dz, u, v);
 	if (face < 0) return make_float3(0.0f, 0.0f, 0.0f);
-	float3 c = tex_fetch(sc, sc.skyTex[face], u, v);
+	const unsigned rgb = texel_rgb(sc, lt.desc[LDS_SKY + face], u, v);
+	float3 c = make_float3(lt.gamma[rgb & 0xFFu], lt.gamma[(rgb >> 8) & 0xFFu], lt.gamma[rgb >> 16]);
 	return make_float3(c.x * sc.skyBrightness, c.y * sc.skyBrightness, c.z * sc.skyBrightness);
 }
 

@@ -41,11 +41,14 @@ __global__ __launch_bounds__(256) void k_raygen(DevScene sc, Batch b, float4* __
 // length, cnt[1] dead slots (refraction under total internal reflection), cnt[2] shaded hits,
 // cnt[3] texel fetches.
 
-__device__ __forceinline__ void scatter_offset(const DevScene& sc, uint32_t key, uint32_t lobe, uint32_t k, float& ox,
+// cs: the 512 (cos, sin) pairs of the reference's tables, which the block keeps in LDS (two scattered look-ups per
+// direction there instead of four in global memory).
+__device__ __forceinline__ void scatter_offset(const float2* __restrict__ cs, uint32_t key, uint32_t lobe, uint32_t k, float& ox,
 											   float& oy, float& oz) {
 	uint32_t phi = rt_draw(key, lobe, k, 0) & 0x1FFu;
 	uint32_t theta = (rt_draw(key, lobe, k, 1) & 0x1FFu) >> 1;
-	float cp = sc.cosT[phi], sp = sc.sinT[phi], ct = sc.cosT[theta], st = sc.sinT[theta];
+	const float2 a = cs[phi], b = cs[theta];
+	float cp = a.x, sp = a.y, ct = b.x, st = b.y;
 	// horizontal * sin(theta) + cos(theta) * UnitZ, lane by lane (src/Triangle.cpp:107-113)
 	ox = cp * st + ct * 0.0f;
 	oy = sp * st + ct * 0.0f;
@@ -69,6 +72,12 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 	__shared__ unsigned s_tot[SHADE_THREADS / 64];
 	__shared__ unsigned s_base[SHADE_THREADS / 64];
 	__shared__ unsigned s_stat[3][SHADE_THREADS / 64];
+	__shared__ float2 s_cs[512];  // (cos, sin) of the reference's 512-entry tables
+	__shared__ float s_gamma[256];
+	__shared__ int4 s_desc[LDS_TEX + 6];
+	for (int i = threadIdx.x; i < 512; i += SHADE_THREADS) s_cs[i] = make_float2(sc.cosT[i], sc.sinT[i]);
+	lds_tables_fill(sc, s_gamma, s_desc, SHADE_THREADS);
+	const LdsTables lt{s_gamma, s_desc};
 	unsigned deadAll = 0, shadedAll = 0, fetchAll = 0;  // thread 0: the block's counts over all its rounds
 	// The grid does not grow with the queue: a block walks over it in steps of the grid's width (every thread
 	// of a block makes the same number of rounds, so the barriers below are uniform).
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 			}
 			else if (rank == -1) {
 				if (sc.hasSky) {
-					val = sky_fetch(sc, dx, dy, dz);
+					val = sky_fetch(sc, lt, dx, dy, dz);
 					fetches = 1;
 				}
 				else
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 							flags |= FLAG_TEX;
 							float u = (alpha * u01.x + beta * u01.z) + g * u2.x;
 							float v = (alpha * u01.y + beta * u01.w) + g * u2.y;
-							texel = tex_fetch_rgb(sc, texId, u, v);
+							texel = tex_fetch_rgb(sc, lt, texId, u, v);
 							fetches = 1;
 						}
 					}
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 			float rx = dx - k2 * nx, ry = dy - k2 * ny, rz = dz - k2 * nz;
 			for (int i = 0; i < S; ++i) {
 				float ox, oy, oz;
-				scatter_offset(sc, key, 0, (uint32_t)i, ox, oy, oz);
+				scatter_offset(s_cs, key, 0, (uint32_t)i, ox, oy, oz);
 				float cx = rx + ox * rough, cy = ry + oy * rough, cz = rz + oz * rough;
 				nRayO[childBase + i] = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)i)));
 				nRayD[childBase + i] = make_float4(cx, cy, cz, (lastNext && miss_is_zero(sc, cx, cy, cz)) ? 2.0f : 0.0f);
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 				float tx = keep ? nx : -nx, ty = keep ? ny : -ny, tz = keep ? nz : -nz;
 				for (int i = 0; i < Dn; ++i) {
 					float ox, oy, oz;
-					scatter_offset(sc, key, 1, (uint32_t)i, ox, oy, oz);
+					scatter_offset(s_cs, key, 1, (uint32_t)i, ox, oy, oz);
 					nRayO[childBase + S + i] = make_float4(hx, hy, hz, __uint_as_float(rt_child_key(key, (uint32_t)(S + i))));
 					const float ex = tx + ox, ey = ty + oy, ez = tz + oz;
 					nRayD[childBase + S + i] = make_float4(ex, ey, ez, (lastNext && miss_is_zero(sc, ex, ey, ez)) ? 2.0f : 0.0f);
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 // The rays of the last recursion level end their paths whatever they hit: a hit returns zero
 // (src/RayTracer.cpp:170), a miss the sky or the background (:148-152).  This is that value, from the ray's
 // any-hit answer; -2 marks a slot without a ray, -3 a ray that was not traced because both outcomes are zero.
-__device__ __forceinline__ float3 last_level_value(const DevScene& sc, int code, const float4* __restrict__ rayD, unsigned slot,
+__device__ __forceinline__ float3 last_level_value(const DevScene& sc, const LdsTables& lt, int code, const float4* __restrict__ rayD, unsigned slot,
 												   unsigned& dead, unsigned& fetches, unsigned& untraced) {
 	float3 val = make_float3(0.0f, 0.0f, 0.0f);
 	if (code == -2) dead++;
@@ -304,7 +313,7 @@ __device__ __forceinline__ float3 last_level_value(const DevScene& sc, int code,
 	else if (code == -1) {
 		if (sc.hasSky) {
 			const float4 D = rayD[slot];
-			val = sky_fetch(sc, D.x, D.y, D.z);
+			val = sky_fetch(sc, lt, D.x, D.y, D.z);
 			fetches++;
 		}
 		else
@@ -326,6 +335,10 @@ __global__ __launch_bounds__(256) void k_gather(DevScene sc, int n, float4* __re
 												unsigned childCap, unsigned* __restrict__ cnt, const unsigned* __restrict__ nDev) {
 	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
 	const int S = sc.nSpec, Dn = sc.nDiff;
+	__shared__ float s_gamma[256];
+	__shared__ int4 s_desc[LDS_TEX + 6];
+	lds_tables_fill(sc, s_gamma, s_desc, 256);
+	const LdsTables lt{s_gamma, s_desc};
 	unsigned dead = 0, fetches = 0, untraced = 0;
 	for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
 		const int2 b = B[j];
@@ -341,7 +354,7 @@ __global__ __launch_bounds__(256) void k_gather(DevScene sc, int n, float4* __re
 		float sx = 0.0f, sy = 0.0f, sz = 0.0f;
 		for (int i = 0; i < S; ++i) {
 			float3 c;
-			if (LAST) c = last_level_value(sc, codes[first + i], childD, first + i, dead, fetches, untraced);
+			if (LAST) c = last_level_value(sc, lt, codes[first + i], childD, first + i, dead, fetches, untraced);
 			else {
 				const float4 v = childA[first + i];
 				c = make_float3(v.x, v.y, v.z);
@@ -366,7 +379,7 @@ __global__ __launch_bounds__(256) void k_gather(DevScene sc, int n, float4* __re
 			if (b.y & FLAG_TIR) {
 				if (LAST) dead++;  // the slot of the refracted ray that does not exist
 			}
-			else if (LAST) rc = last_level_value(sc, codes[first + S], childD, first + S, dead, fetches, untraced);
+			else if (LAST) rc = last_level_value(sc, lt, codes[first + S], childD, first + S, dead, fetches, untraced);
 			else {
 				const float4 v = childA[first + S];
 				rc = make_float3(v.x, v.y, v.z);
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(256) void k_gather(DevScene sc, int n, float4* __re
 			float dx = 0.0f, dy = 0.0f, dz = 0.0f;
 			for (int i = 0; i < Dn; ++i) {
 				float3 c;
-				if (LAST) c = last_level_value(sc, codes[first + S + i], childD, first + S + i, dead, fetches, untraced);
+				if (LAST) c = last_level_value(sc, lt, codes[first + S + i], childD, first + S + i, dead, fetches, untraced);
 				else {
 					const float4 v = childA[first + S + i];
 					c = make_float3(v.x, v.y, v.z);
@@ -403,9 +416,9 @@ __global__ __launch_bounds__(256) void k_gather(DevScene sc, int n, float4* __re
 			oz = sz + dz * ad;
 			if (b.y & FLAG_TEX) {
 				const unsigned rgb = (unsigned)b.y >> 8;
-				ox = ox * sc.gammaT[rgb & 0xFFu];
-				oy = oy * sc.gammaT[(rgb >> 8) & 0xFFu];
-				oz = oz * sc.gammaT[rgb >> 16];
+				ox = ox * lt.gamma[rgb & 0xFFu];
+				oy = oy * lt.gamma[(rgb >> 8) & 0xFFu];
+				oz = oz * lt.gamma[rgb >> 16];
 			}
 		}
 		A[j] = make_float4(ox, oy, oz, 0.0f);

@@ -368,7 +368,7 @@ DevScene make_dev_scene(const rtx_scene* s) {
 
 int upload_textures(rtx_scene* s) {
 	if (!s->texDirty) return RTX_OK;
-	HIPCHK(s->dTexels.alloc(std::max<size_t>(s->texels.size(), 16)));
+	HIPCHK(s->dTexels.alloc(s->texels.size() + 16));  // a texel is read with a four-byte load: the last one's fourth byte must exist
 	if (!s->texels.empty())
 		HIPCHK(hipMemcpy(s->dTexels.p, s->texels.data(), s->texels.size(), hipMemcpyHostToDevice));
 	std::vector<int4> desc(std::max<size_t>(s->texInfo.size(), 1));
