@@ -196,6 +196,7 @@ struct rtx_scene {
 	int skyTex[6] = {-1, -1, -1, -1, -1, -1};
 	int tileFirst = 0, tileStride = 1, tileCount = -1;
 	uint64_t arenaLimit = 0;
+	size_t defaultBudget = 0;  // the default arena budget as last worked out from the free device memory (0: not yet)
 	bool instrumented = false;
 	// host copies
 	std::vector<HostTri> tris;
@@ -684,13 +685,22 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 	// small tile share without multiplying the arena of a big one.
 	const long long mergeBlocks = std::max(blocksPerFrame, (s->mergeBlocks / blocksPerFrame) * blocksPerFrame);
 
-	size_t freeB = 0, totalB = 0;
-	HIPCHK(hipMemGetInfo(&freeB, &totalB));
 	// Default budget: 60 % of what is free, at most 64 GiB.  Each batch costs one synchronisation plus, per
 	// level, the latency of its longest ray, so bigger batches are better; allocating and mapping hundreds of GB
 	// costs seconds, so the arena is not grown beyond that.  The arena never exceeds the budget.
-	const size_t budget = s->arenaLimit ? (size_t)s->arenaLimit
-										: std::min<size_t>((size_t)((double)(freeB + s->arena.n) * 0.6), (size_t)64 << 30);
+	// The driver is asked for the free memory (tens of microseconds, once per frame otherwise) only when the answer can
+	// matter: the first time, and whenever a batch would want more than the arena holds.
+	auto default_budget = [&](size_t& out) {
+		size_t freeB = 0, totalB = 0;
+		HIPCHK(hipMemGetInfo(&freeB, &totalB));
+		out = std::min<size_t>((size_t)((double)(freeB + s->arena.n) * 0.6), (size_t)64 << 30);
+		return (int)RTX_OK;
+	};
+	if (!s->arenaLimit && !s->defaultBudget) {
+		const int rcb = default_budget(s->defaultBudget);
+		if (rcb) return rcb;
+	}
+	size_t budget = s->arenaLimit ? (size_t)s->arenaLimit : s->defaultBudget;
 	auto over_budget = [&](double needBytes) {
 		return fail(RTX_ERR_MEMORY, "the ray queues of one 4x4-pixel block need " + std::to_string((unsigned long long)(needBytes / 1048576.0) + 1) +
 										" MiB at the ray populations seen so far (max_depth " + std::to_string(s->maxDepth) + ", " +
@@ -701,11 +711,19 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 
 	int attempts = 0;  // tries of the batch that starts at g0
 	int rc = RTX_OK;
+	bool budgetFresh = false;  // the default budget has been refreshed during this call
 	for (long long g0 = gBegin; g0 < gEnd;) {
 		// ---- plan this batch from the capacities as they stand now (an overflow or a first success changes them)
 		double ratio[MAX_DEPTH + 2];
 		for (int lv = 0; lv <= levels; ++lv) ratio[lv] = lv == 0 ? 1.0 : s->capRatio[lv];
 		double perSample = bytes_per_sample(ratio, levels);
+		if (!s->arenaLimit && !budgetFresh && perSample * SAMPLES_PER_BLOCK + fixedBytes > (double)budget) {
+			const int rcb = default_budget(s->defaultBudget);  // before anything is refused: what is free now
+			if (rcb) return rcb;
+			budget = s->defaultBudget;
+			budgetFresh = true;
+			continue;
+		}
 		if (perSample * SAMPLES_PER_BLOCK + fixedBytes > (double)budget) {
 			// Not even one pixel block fits.  Levels beyond capKnown are guesses: they share what the known levels
 			// leave of the budget, equally, and the device reports which of them was too small.
@@ -737,6 +755,14 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 		// The arena's size is kept a multiple of 4 KiB (rounded down: never beyond the budget), because the ray sets
 		// are carved from its top end: a size that is not a multiple of 16 would put every float4 of them at a
 		// misaligned address, and the scalar loads of the wave-per-ray kernel would read the wrong words.
+		if (!s->arenaLimit && needAll + 4096.0 > (double)s->arena.n && !budgetFresh) {
+			// the arena would have to grow: what is free now decides how far (the loop plans this batch once more)
+			const int rcb = default_budget(s->defaultBudget);
+			if (rcb) return rcb;
+			budget = s->defaultBudget;
+			budgetFresh = true;
+			continue;
+		}
 		size_t want = (size_t)std::min((double)budget, needAll + 4096.0) & ~(size_t)4095;
 		// an arena that is at least nearly as big as wanted is used as it is rather than reallocated
 		if (s->arena.n && (double)s->arena.n >= 0.9 * (double)want && s->arena.n <= budget) want = std::max(want, s->arena.n);
@@ -1454,6 +1480,7 @@ RTX_API int rtx_scene_set_tiles(rtx_scene* s, int first, int stride, int count) 
 RTX_API int rtx_scene_set_arena_bytes(rtx_scene* s, uint64_t bytes) {
 	if (!s) return fail(RTX_ERR_ARG, "scene is null");
 	s->arenaLimit = bytes;
+	s->defaultBudget = 0;
 	return RTX_OK;
 }
 
