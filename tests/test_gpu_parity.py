@@ -769,6 +769,15 @@ def test_deep_branching_recursion_grows_its_queues_within_the_arena_limit(libs, 
     rt.render(2, 1)
     assert rt.stats()["queue_retries"] == 0
     assert_bits_equal(want[..., :3], rt.accum()[..., :3], "accumulator, frame 2")
+    # a limit between what the populations need (a few hundred MiB for one pixel block) and what the first guesses would
+    # ask for: the levels whose true counts are known must be planned with those counts, not with their guesses
+    mid = api.RayTracer(0)
+    mid.load_scene(sc, nodes)
+    mid.set_arena_bytes(512 << 20)
+    mid.reset()
+    mid.render(1, 1)
+    mid.render(2, 1)
+    assert_bits_equal(want[..., :3], mid.accum()[..., :3], "accumulator under a 512 MiB limit")
     small = api.RayTracer(0)
     small.load_scene(sc, nodes)
     small.set_arena_bytes(24 << 20)
