@@ -17,7 +17,7 @@ HOST_SO = os.path.join(PKG, "librtx_host.so")
 CLI_BIN = os.path.join(PKG, "RayTracer")
 
 HIP_SOURCES = ["rtx_hip.hip"]
-HOST_SOURCES = ["rtx_host.cpp", "rtx_config.cpp", "rtx_image.cpp", "rtx_jpeg.cpp"]
+HOST_SOURCES = ["rtx_host.cpp", "rtx_config.cpp", "rtx_image.cpp", "rtx_image_formats.cpp", "rtx_jpeg.cpp"]
 HIP_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
              "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-fvisibility=hidden"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-mavx2", "-mfma", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wextra"]

@@ -1,5 +1,5 @@
-// Image file I/O for the host side: 8-bit RGB texture loading (binary PPM/PGM, 24/32-bit BMP,
-// uncompressed or RLE TGA, non-interlaced 8-bit PNG, JPEG via rtx_jpeg.cpp) with the reference's vertical flip
+// Image file I/O for the host side: 8-bit RGB texture loading (binary PPM/PGM, uncompressed or RLE TGA, PNG,
+// JPEG via rtx_jpeg.cpp, BMP/GIF/PSD/PIC/HDR via rtx_image_formats.cpp) with the reference's vertical flip
 // (src/Texture.cpp:6-7: stbi_set_flip_vertically_on_load(1), 3 channels forced), and the PNG
 // writer behind out_%03d.png (src/RayTracer.cpp:263-269: 3 channels, stride 3*width).
 // Self-contained: no image library is linked.
@@ -382,33 +382,6 @@ bool load_pnm(const std::vector<uint8_t>& f, Image& img) {
 	return true;
 }
 
-bool load_bmp(const std::vector<uint8_t>& f, Image& img) {
-	if (f.size() < 54 || f[0] != 'B' || f[1] != 'M') return false;
-	auto u32 = [&](size_t o) { return (uint32_t)f[o] | (f[o + 1] << 8) | (f[o + 2] << 16) | ((uint32_t)f[o + 3] << 24); };
-	uint32_t off = u32(10);
-	int32_t w = (int32_t)u32(18), h = (int32_t)u32(22);
-	int bpp = f[28] | (f[29] << 8);
-	if (u32(30) != 0 || (bpp != 24 && bpp != 32) || w <= 0 || h == 0) return false;
-	const bool bottomUp = h > 0;
-	if (h < 0) h = -h;
-	const size_t stride = (((size_t)w * bpp / 8) + 3) & ~(size_t)3;
-	if (off + stride * h > f.size()) return false;
-	img.w = w;
-	img.h = h;
-	img.rgb.resize((size_t)w * h * 3);
-	for (int y = 0; y < h; ++y) {
-		const uint8_t* row = &f[off + stride * (bottomUp ? (h - 1 - y) : y)];
-		for (int x = 0; x < w; ++x) {
-			const uint8_t* p = row + (size_t)x * bpp / 8;
-			uint8_t* d = &img.rgb[((size_t)y * w + x) * 3];
-			d[0] = p[2];
-			d[1] = p[1];
-			d[2] = p[0];
-		}
-	}
-	return true;
-}
-
 bool load_tga(const std::vector<uint8_t>& f, Image& img) {
 	if (f.size() < 18) return false;
 	const int idlen = f[0], cmap = f[1], type = f[2];
@@ -466,10 +439,23 @@ bool load_tga(const std::vector<uint8_t>& f, Image& img) {
 
 // Decodes to top-down RGB, then flips vertically: after this call row 0 is the bottom row of
 // the picture, which is what Texture::data holds in the reference.
+// The container is chosen by signature in the reference's order (stb_image.h:1019-1063: JPEG, PNG, BMP, GIF, PSD,
+// PIC, PNM, HDR and, having no signature, TGA last); a file that carries a signature and fails to decode is not
+// offered to the later decoders.
 bool load_texture_file(const std::string& path, Image& img) {
 	std::vector<uint8_t> f;
 	if (!read_file(path, f)) return false;
-	bool ok = load_jpeg(f, img) || load_png(f, img) || load_pnm(f, img) || load_bmp(f, img) || load_tga(f, img);
+	static const uint8_t pngSig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+	bool ok;
+	if (f.size() >= 2 && f[0] == 0xFF && f[1] == 0xD8) ok = load_jpeg(f, img);
+	else if (f.size() >= 8 && !std::memcmp(f.data(), pngSig, 8)) ok = load_png(f, img);
+	else if (is_bmp(f)) ok = load_bmp(f, img);
+	else if (is_gif(f)) ok = load_gif(f, img);
+	else if (is_psd(f)) ok = load_psd(f, img);
+	else if (is_pic(f)) ok = load_pic(f, img);
+	else if (f.size() >= 2 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) ok = load_pnm(f, img);
+	else if (is_hdr(f)) ok = load_hdr(f, img);
+	else ok = load_tga(f, img);
 	if (!ok) return false;
 	const size_t stride = (size_t)img.w * 3;
 	std::vector<uint8_t> tmp(stride);

@@ -23,6 +23,8 @@ def main():
     cases = [c for c in image_cases.jpeg_cases(rng, keep=0.008) if len(c[1]) < 4000]
     rng = np.random.default_rng(12)
     cases += [c for c in image_cases.lossless_cases(rng) if "37x23" in c[0] or "5x9" in c[0]]
+    rng = np.random.default_rng(13)
+    cases += [c for c in image_cases.more_cases(rng) if ("37x23" in c[0] or "5x9" in c[0] or "ramp." in c[0]) and len(c[1]) < 6000]
     arrays, names = {}, []
     with tempfile.TemporaryDirectory() as d:
         for k, (name, data) in enumerate(cases):

@@ -89,3 +89,358 @@ def lossless_cases(rng):
         yield "l_%s.tga" % tag, _save(Image.fromarray(a[:, :, 0]), "TGA")
         yield "rgb_%s.ppm" % tag, _save(rgb, "PPM")
         yield "l_%s.pgm" % tag, _save(Image.fromarray(a[:, :, 0]), "PPM")
+
+
+# ---- containers Pillow cannot write, or cannot write in every flavour: made by hand ---------------------------------
+
+def bmp_file(w, h, bpp, rows, hsz=40, compress=0, masks=None, palette=None, top_down=False, gap=0):
+    """rows: h byte strings (top row first), unpadded; palette: list of (r, g, b)."""
+    data = b""
+    order = rows if top_down else rows[::-1]
+    for r in order:
+        data += r + b"\0" * ((-len(r)) & 3)
+    if hsz == 12:
+        head = struct.pack("<IHHHH", 12, w, h, 1, bpp)
+    else:
+        head = struct.pack("<IiiHHIIiiII", hsz, w, -h if top_down else h, 1, bpp, compress, len(data), 2835, 2835, 0, 0)
+        if hsz == 56:
+            head += struct.pack("<IIII", *(masks or (0, 0, 0, 0)))
+        elif hsz in (108, 124):
+            head += struct.pack("<IIII", *(masks or (0, 0, 0, 0))) + b"\0" * 52 + (b"\0" * 16 if hsz == 124 else b"")
+        elif compress == 3:
+            head += struct.pack("<III", *masks[:3])
+    pal = b""
+    for (r, g, b) in palette or []:
+        pal += bytes([b, g, r]) + (b"" if hsz == 12 else b"\0")
+    pal += b"\xAA" * gap
+    off = 14 + len(head) + len(pal)
+    return b"BM" + struct.pack("<IHHI", off + len(data), 0, 0, off) + head + pal + data
+
+
+def _pack_bits(idx, bits):
+    out = bytearray()
+    per = 8 // bits
+    for i in range(0, len(idx), per):
+        v = 0
+        for k in range(per):
+            v <<= bits
+            if i + k < len(idx):
+                v |= int(idx[i + k])
+        out.append(v)
+    return bytes(out)
+
+
+def bmp_cases(rng):
+    from PIL import Image
+    for (w, h) in [(37, 23), (1, 1), (8, 8), (5, 9), (33, 4)]:
+        tag = "%dx%d" % (w, h)
+        a = rng.integers(0, 256, (h, w, 4)).astype(np.uint8)
+        rgb = Image.fromarray(a[:, :, :3])
+        yield "pil_1_%s.bmp" % tag, _save(rgb.convert("1"), "BMP")
+        yield "pil_l_%s.bmp" % tag, _save(Image.fromarray(a[:, :, 0]), "BMP")
+        yield "pil_p_%s.bmp" % tag, _save(rgb.convert("P", palette=Image.ADAPTIVE, colors=40), "BMP")
+        yield "pil_rgba_%s.bmp" % tag, _save(Image.fromarray(a, "RGBA"), "BMP")
+        pal = [tuple(int(v) for v in rng.integers(0, 256, 3)) for _ in range(256)]
+        for bits, hsz, td in [(1, 40, False), (4, 40, False), (4, 108, True), (8, 40, True), (8, 124, False), (8, 56, False), (1, 12, False), (4, 12, True), (8, 12, False)]:
+            n = 1 << bits
+            top = n - 4 if hsz == 12 and n > 4 else n      # the 12-byte header's last four entries are not read by stb
+            idx = rng.integers(0, max(top, 1) if not (hsz == 12 and bits == 1) else 1, (h, w))
+            if hsz == 12 and bits == 1:
+                # two entries in the file, minus four read: stb refuses the file; keep one such case as a refusal
+                continue
+            rows = [_pack_bits(r, bits) for r in idx]
+            yield "pal%d_h%d_%s%s.bmp" % (bits, hsz, "td_" if td else "", tag), bmp_file(w, h, bits, rows, hsz=hsz, palette=pal[:n], top_down=td,
+                                                                                        gap=(8 if hsz == 40 and bits == 4 else 0))
+        v16 = rng.integers(0, 65536, (h, w)).astype("<u2")
+        yield "x555_%s.bmp" % tag, bmp_file(w, h, 16, [r.tobytes() for r in v16])
+        yield "r565_%s.bmp" % tag, bmp_file(w, h, 16, [r.tobytes() for r in v16], compress=3, masks=(0xF800, 0x07E0, 0x001F))
+        yield "r565_v4_%s.bmp" % tag, bmp_file(w, h, 16, [r.tobytes() for r in v16], hsz=108, compress=3, masks=(0xF800, 0x07E0, 0x001F, 0))
+        yield "a4444_v4_%s.bmp" % tag, bmp_file(w, h, 16, [r.tobytes() for r in v16], hsz=108, compress=3, masks=(0x0F00, 0x00F0, 0x000F, 0xF000), top_down=True)
+        yield "odd16_%s.bmp" % tag, bmp_file(w, h, 16, [r.tobytes() for r in v16], compress=3, masks=(0xFE00, 0x01C0, 0x0003))
+        v32 = rng.integers(0, 1 << 32, (h, w), dtype=np.uint64).astype("<u4")
+        yield "x888_%s.bmp" % tag, bmp_file(w, h, 32, [r.tobytes() for r in v32])
+        yield "bgr32_%s.bmp" % tag, bmp_file(w, h, 32, [r.tobytes() for r in v32], compress=3, masks=(0x000000FF, 0x0000FF00, 0x00FF0000))
+        yield "hi32_%s.bmp" % tag, bmp_file(w, h, 32, [r.tobytes() for r in v32], hsz=108, compress=3, masks=(0xFF000000, 0x00FC0000, 0x0003E000, 0x7F))
+        yield "argb_v4_%s.bmp" % tag, bmp_file(w, h, 32, [r.tobytes() for r in v32], hsz=108, compress=3, masks=(0xFF0000, 0xFF00, 0xFF, 0xFF000000))
+        yield "rgb24_v4_%s.bmp" % tag, bmp_file(w, h, 24, [r[:, ::-1].tobytes() for r in a[:, :, :3]], hsz=108, masks=(0xFF0000, 0xFF00, 0xFF, 0))
+        yield "rgb24_os2_%s.bmp" % tag, bmp_file(w, h, 24, [r[:, ::-1].tobytes() for r in a[:, :, :3]], hsz=12)
+
+
+def _gif_lzw(idx, min_bits, with_clear=True):
+    """Plain LZW for GIF: variable code width from min_bits + 1, table cleared when full."""
+    clear, end = 1 << min_bits, (1 << min_bits) + 1
+    out = bytearray()
+    acc = n = 0
+    width = min_bits + 1
+
+    def emit(code):
+        nonlocal acc, n
+        acc |= code << n
+        n += width
+        while n >= 8:
+            out.append(acc & 255)
+            acc >>= 8
+            n -= 8
+    table = {(i,): i for i in range(clear)}
+    nxt = end + 1
+    emit(clear)
+    cur = ()
+    for v in idx:
+        v = int(v)
+        if cur + (v,) in table:
+            cur = cur + (v,)
+            continue
+        emit(table[cur])
+        table[cur + (v,)] = nxt
+        nxt += 1
+        if nxt > (1 << width) and width < 12:
+            width += 1
+        elif nxt >= 4096:
+            emit(clear)
+            table = {(i,): i for i in range(clear)}
+            nxt = end + 1
+            width = min_bits + 1
+        cur = (v,)
+    if cur:
+        emit(table[cur])
+    emit(end)
+    if n:
+        out.append(acc & 255)
+    blocks = b""
+    for i in range(0, len(out), 255):
+        chunk = bytes(out[i:i + 255])
+        blocks += bytes([len(chunk)]) + chunk
+    return bytes([min_bits]) + blocks + b"\0"
+
+
+def gif_file(cw, ch, gpal, frame, bg=0, lpal=None, transparent=None, interlace=False, version=b"89a", extra=b""):
+    """frame: (x, y, index array).  gpal/lpal: lists of (r, g, b) whose length is a power of two >= 2, or None."""
+    def table_bits(p):
+        return max(len(p).bit_length() - 2, 0)
+    out = b"GIF" + version + struct.pack("<HHBBB", cw, ch, (0x80 | table_bits(gpal)) if gpal else 0, bg, 0)
+    if gpal:
+        out += b"".join(bytes(c) for c in gpal)
+    out += extra
+    if transparent is not None:
+        out += b"\x21\xF9\x04" + struct.pack("<BHB", 1, 7, transparent) + b"\0"
+    x, y, idx = frame
+    fh, fw = idx.shape
+    flags = (0x40 if interlace else 0) | ((0x80 | table_bits(lpal)) if lpal else 0)
+    out += b"\x2C" + struct.pack("<HHHHB", x, y, fw, fh, flags)
+    if lpal:
+        out += b"".join(bytes(c) for c in lpal)
+    rows = list(range(fh))
+    if interlace:
+        rows = list(range(0, fh, 8)) + list(range(4, fh, 8)) + list(range(2, fh, 4)) + list(range(1, fh, 2))
+    n = len(lpal or gpal)
+    out += _gif_lzw(idx[rows].reshape(-1), max(2, (n - 1).bit_length()))
+    return out + b"\x3B"
+
+
+def gif_cases(rng):
+    from PIL import Image
+    for (w, h) in [(37, 23), (1, 1), (8, 8), (5, 9), (64, 40)]:
+        tag = "%dx%d" % (w, h)
+        a = picture(rng, w, h, 0)
+        rgb = Image.fromarray(a)
+        for colors in (256, 16, 2):
+            p = rgb.convert("P", palette=Image.ADAPTIVE, colors=colors)
+            yield "pil_p%d_%s.gif" % (colors, tag), _save(p, "GIF")
+            yield "pil_p%d_i_%s.gif" % (colors, tag), _save(p, "GIF", interlace=1)
+        yield "pil_tr_%s.gif" % tag, _save(rgb.convert("P", palette=Image.ADAPTIVE, colors=8), "GIF", transparency=3)
+        yield "pil_l_%s.gif" % tag, _save(Image.fromarray(a[:, :, 0]), "GIF")
+        for n in (2, 4, 32, 256):
+            pal = [tuple(int(v) for v in rng.integers(0, 256, 3)) for _ in range(n)]
+            pal2 = [tuple(int(v) for v in rng.integers(0, 256, 3)) for _ in range(n)]
+            idx = rng.integers(0, n, (h, w))
+            yield "g%d_%s.gif" % (n, tag), gif_file(w, h, pal, (0, 0, idx))
+            yield "g%d_il_%s.gif" % (n, tag), gif_file(w, h, pal, (0, 0, idx), interlace=True, version=b"87a")
+            yield "g%d_tr_%s.gif" % (n, tag), gif_file(w, h, pal, (0, 0, idx), transparent=1, bg=0)
+            yield "g%d_lp_%s.gif" % (n, tag), gif_file(w, h, pal, (0, 0, idx), lpal=pal2, transparent=n - 1, bg=1,
+                                                      extra=b"\x21\xFE\x05hello\x03abc\0")
+            yield "g%d_nolocal_%s.gif" % (n, tag), gif_file(w, h, None, (0, 0, idx), lpal=pal2)
+            if w > 4 and h > 4:
+                sub = idx[2:h - 1, 1:w - 2]
+                yield "g%d_sub_%s.gif" % (n, tag), gif_file(w, h, pal, (1, 2, sub), bg=n - 1)
+                yield "g%d_sub0_%s.gif" % (n, tag), gif_file(w, h, pal, (1, 2, sub), bg=0, transparent=0)
+                yield "g%d_subil_%s.gif" % (n, tag), gif_file(w, h, pal, (1, 2, sub), bg=1, interlace=True, transparent=1, lpal=pal2)
+    # a long picture of noise fills the code table several times over
+    idx = rng.integers(0, 256, (200, 150))
+    pal = [tuple(int(v) for v in rng.integers(0, 256, 3)) for _ in range(256)]
+    yield "g256_big.gif", gif_file(150, 200, pal, (0, 0, idx))
+    yield "g256_big_il.gif", gif_file(150, 200, pal, (0, 0, idx), interlace=True)
+
+
+def _packbits(row):
+    """PackBits with short runs, so that both literal and repeat packets (and the no-op byte) appear."""
+    out = bytearray()
+    i = 0
+    row = bytes(row)
+    while i < len(row):
+        j = i
+        while j + 1 < len(row) and row[j + 1] == row[i] and j - i < 127:
+            j += 1
+        if j > i:
+            out += bytes([257 - (j - i + 1), row[i]])
+            i = j + 1
+        else:
+            j = i
+            while j + 1 < len(row) and row[j + 1] != row[j] and j - i < 127:
+                j += 1
+            out += bytes([j - i]) + row[i:j + 1]
+            i = j + 1
+        if len(out) % 7 == 0:
+            out.append(128)
+    return bytes(out)
+
+
+def psd_file(planes, depth=8, rle=False, resources=b"", mode=3):
+    """planes: (channels, h, w) uint8 or uint16."""
+    c, h, w = planes.shape
+    out = b"8BPS" + struct.pack(">H6xHIIHH", 1, c, h, w, depth, mode)
+    out += struct.pack(">I", 0) + struct.pack(">I", len(resources)) + resources + struct.pack(">I", 4) + b"\0\0\0\0"
+    out += struct.pack(">H", 1 if rle else 0)
+    if rle:
+        packed = [_packbits(planes[k, y].astype(">u2" if depth == 16 else np.uint8).tobytes()) for k in range(c) for y in range(h)]
+        out += b"".join(struct.pack(">H", len(p)) for p in packed) + b"".join(packed)
+    else:
+        out += planes.astype(">u2" if depth == 16 else np.uint8).tobytes()
+    return out
+
+
+def psd_cases(rng):
+    for (w, h) in [(37, 23), (1, 1), (8, 8), (5, 9)]:
+        tag = "%dx%d" % (w, h)
+        for c in (1, 3, 4, 5):
+            p8 = rng.integers(0, 256, (c, h, w)).astype(np.uint8)
+            p8[:, :, : w // 2] = p8[:, :, :1]             # runs for the packed rows
+            if c >= 4:
+                p8[3, : h // 2] = rng.choice([0, 255, 128, 1, 254], (h // 2, w))
+            yield "psd8_c%d_%s.psd" % (c, tag), psd_file(p8)
+            yield "psd8_c%d_rle_%s.psd" % (c, tag), psd_file(p8, rle=True, resources=b"8BIM" + b"\0" * 12)
+            p16 = rng.integers(0, 65536, (c, h, w)).astype(np.uint16)
+            yield "psd16_c%d_%s.psd" % (c, tag), psd_file(p16, depth=16)
+
+
+def pic_file(w, h, packets, rows):
+    """packets: list of (type, channel mask); rows[y][k] = the encoded bytes of packet k in row y."""
+    out = bytes([0x53, 0x80, 0xF6, 0x34]) + struct.pack(">f", 3.7) + b"a comment".ljust(80, b"\0") + b"PICT"
+    out += struct.pack(">HHfHH", w, h, 1.0, 3, 0)
+    for k, (typ, mask) in enumerate(packets):
+        out += bytes([1 if k + 1 < len(packets) else 0, 8, typ, mask])
+    for y in range(h):
+        for k in range(len(packets)):
+            out += rows[y][k]
+    return out
+
+
+def _pic_encode(rng, px, typ):
+    """px: (w, nch) uint8 values of the packet's channels in one row."""
+    w = px.shape[0]
+    if typ == 0:
+        return px.tobytes()
+    out = b""
+    x = 0
+    while x < w:
+        run = 1
+        while x + run < w and run < 100 and (px[x + run] == px[x]).all():
+            run += 1
+        if typ == 1:
+            out += bytes([run]) + px[x].tobytes()
+            x += run
+        elif run > 1 or rng.random() < 0.3:
+            long_form = run == 1 or rng.random() < 0.3          # a count byte of 128 announces a 16-bit count
+            out += (bytes([128]) + struct.pack(">H", run) if long_form else bytes([127 + run])) + px[x].tobytes()
+            x += run
+        else:
+            n = min(w - x, int(rng.integers(1, 6)))
+            out += bytes([n - 1]) + px[x:x + n].tobytes()
+            x += n
+    return out
+
+
+def pic_cases(rng):
+    for (w, h) in [(37, 23), (1, 1), (8, 8), (5, 9)]:
+        tag = "%dx%d" % (w, h)
+        a = rng.integers(0, 256, (h, w, 4)).astype(np.uint8)
+        a[:, : w // 2] = a[:, :1]
+        for name, packets in [("raw", [(0, 0xE0)]), ("rle", [(1, 0xE0)]), ("mix", [(2, 0xE0)]), ("mix_a", [(2, 0xE0), (2, 0x10)]),
+                              ("split", [(2, 0x80), (1, 0x40), (0, 0x30)]), ("rg", [(2, 0xC0)])]:
+            rows = []
+            for y in range(h):
+                enc = []
+                for typ, mask in packets:
+                    ch = [i for i in range(4) if mask & (0x80 >> i)]
+                    enc.append(_pic_encode(rng, a[y][:, ch], typ))
+                rows.append(enc)
+            yield "pic_%s_%s.pic" % (name, tag), pic_file(w, h, packets, rows)
+
+
+def hdr_file(rgbe, rle, magic=b"#?RADIANCE", extra=b"EXPOSURE=1.0\n"):
+    h, w, _ = rgbe.shape
+    out = magic + b"\n" + extra + b"FORMAT=32-bit_rle_rgbe\n\n" + b"-Y %d +X %d\n" % (h, w)
+    if not rle:
+        return out + rgbe.tobytes()
+    for y in range(h):
+        out += bytes([2, 2, w >> 8, w & 255])
+        for k in range(4):
+            row = rgbe[y, :, k]
+            x = 0
+            while x < w:
+                run = 1
+                while x + run < w and run < 127 and row[x + run] == row[x]:
+                    run += 1
+                if run > 2:
+                    out += bytes([128 + run, int(row[x])])
+                    x += run
+                else:
+                    n = min(w - x, 5)
+                    out += bytes([n]) + row[x:x + n].tobytes()
+                    x += n
+    return out
+
+
+def hdr_cases(rng):
+    for (w, h) in [(37, 23), (1, 1), (8, 8), (5, 9), (130, 3)]:
+        tag = "%dx%d" % (w, h)
+        rgbe = rng.integers(0, 256, (h, w, 4)).astype(np.uint8)
+        rgbe[..., 3] = rng.integers(118, 140, (h, w))        # exponents around 1.0, where the tone curve has detail
+        rgbe[::3, ::4, 3] = 0
+        rgbe[:, : w // 2, :2] = 77
+        yield "flat_%s.hdr" % tag, hdr_file(rgbe, False)
+        yield "rle_%s.hdr" % tag, hdr_file(rgbe, True, magic=b"#?RGBE", extra=b"# made by hand\nGAMMA=1\n")
+    full = np.zeros((16, 256, 4), np.uint8)                  # every mantissa at a spread of exponents
+    full[..., 0] = np.arange(256)
+    full[..., 1] = np.arange(256)[::-1]
+    full[..., 2] = (np.arange(256) * 7) % 256
+    full[..., 3] = (np.arange(16) + 121)[:, None]
+    yield "ramp.hdr", hdr_file(full, True)
+    yield "ramp_flat.hdr", hdr_file(full, False)
+
+
+def more_cases(rng):
+    for gen in (bmp_cases, gif_cases, psd_cases, pic_cases, hdr_cases):
+        yield from gen(rng)
+
+
+def refused_cases(rng):
+    """Files the reference's loader turns down (without crashing): the product must turn them down too."""
+    from PIL import Image
+    a = rng.integers(0, 256, (6, 9, 3)).astype(np.uint8)
+    idx = rng.integers(0, 4, (6, 9))
+    pal = [(1, 2, 3), (40, 50, 60), (200, 100, 0), (255, 255, 255)]
+    yield "rle8.bmp", bmp_file(9, 6, 8, [bytes(r) for r in idx], compress=1, palette=pal)
+    yield "no_masks_v4.bmp", bmp_file(9, 6, 16, [bytes(18)] * 6, hsz=108, masks=(0, 0, 0, 0))
+    yield "same_masks.bmp", bmp_file(9, 6, 32, [bytes(36)] * 6, compress=3, masks=(0xFF, 0xFF, 0xFF))
+    yield "two_planes.bmp", bmp_file(9, 6, 24, [bytes(27)] * 6).replace(struct.pack("<HH", 1, 24), struct.pack("<HH", 2, 24), 1)
+    yield "trailer_only.gif", gif_file(9, 6, pal, (0, 0, idx)).split(b"\x2C")[0] + b"\x3B"
+    yield "frame_outside.gif", gif_file(8, 6, pal, (0, 0, idx))
+    yield "no_table.gif", gif_file(9, 6, None, (0, 0, idx), lpal=pal).replace(b"\x2C" + struct.pack("<HHHHB", 0, 0, 9, 6, 0x81), b"\x2C" + struct.pack("<HHHHB", 0, 0, 9, 6, 0), 1)
+    yield "cmyk.psd", psd_file(np.zeros((4, 6, 9), np.uint8), mode=4)
+    yield "zip.psd", psd_file(np.zeros((3, 6, 9), np.uint8))[:-2 - 3 * 54] + struct.pack(">H", 2) + bytes(3 * 54)
+    yield "depth1.psd", psd_file(np.zeros((3, 6, 9), np.uint8), depth=1)
+    yield "xyze.hdr", hdr_file(np.zeros((6, 9, 4), np.uint8), False).replace(b"32-bit_rle_rgbe", b"32-bit_rle_xyze")
+    yield "plus_y.hdr", hdr_file(np.zeros((6, 9, 4), np.uint8), False).replace(b"-Y 6", b"+Y 6")
+    yield "wide.ppm", b"P6\n9 6\n65535\n" + bytes(9 * 6 * 6)
+    yield "ascii.ppm", b"P3\n1 1\n255\n1 2 3\n"
+    yield "empty.bin", b""

@@ -128,7 +128,8 @@ def test_tonemap_table_is_the_host_tonemap(native_libs):
 def test_texture_loaders_match_reference_goldens(native_libs, tmp_path):
     """tests/golden/images.npz holds image files and what the reference's stb_image decodes from them (three
     channels, bottom row first, src/Texture.cpp:4-8): JPEG baseline/progressive/subsampled/grey/CMYK, PNG in all
-    bit depths incl. 16-bit, palette and Adam7, BMP, TGA (raw and RLE), PPM/PGM."""
+    bit depths incl. 16-bit, palette and Adam7, TGA (raw and RLE), PPM/PGM, BMP with colour tables and channel masks,
+    GIF, PSD, PIC and HDR."""
     g = np.load(os.path.join(ROOT, "tests", "golden", "images.npz"))
     names = [str(n) for n in g["names"]]
     assert len(names) >= 30 and any(n.endswith(".jpg") for n in names)
@@ -143,6 +144,28 @@ def test_texture_loaders_match_reference_goldens(native_libs, tmp_path):
         f.write(g["file_0"].tobytes()[:200])
     with pytest.raises(api.RtxError):
         api.load_texture(str(tmp_path / "broken.jpg"))
+
+
+def test_bmp_version_5_header_decodes_like_version_4(native_libs, tmp_path):
+    """The reference's loader stops on an assertion of its own 128-byte read buffer when a 16-, 24- or 32-bit BMP has
+    the 124-byte header (include/stb_image.h:5227), so those files have no reference pixels to compare with; a build
+    without assertions reads them like the 108-byte header, and that is what the product does."""
+    import image_cases
+    rng = np.random.default_rng(3)
+    w, h = 13, 7
+    v16 = rng.integers(0, 65536, (h, w)).astype("<u2")
+    v32 = rng.integers(0, 1 << 32, (h, w), dtype=np.uint64).astype("<u4")
+    rgb = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    for bpp, rows, compress, masks in [(16, v16, 3, (0x0F00, 0x00F0, 0x000F, 0xF000)), (32, v32, 3, (0xFF000000, 0x00FC0000, 0x0003E000, 0x7F)),
+                                       (24, rgb, 0, (0, 0, 0, 0))]:
+        out = []
+        for hsz in (108, 124):
+            path = str(tmp_path / ("v%d_%d.bmp" % (hsz, bpp)))
+            with open(path, "wb") as f:
+                f.write(image_cases.bmp_file(w, h, bpp, [r.tobytes() for r in rows], hsz=hsz, compress=compress, masks=masks))
+            out.append(api.load_texture(path))
+        assert out[0].shape == (h, w, 3) and np.array_equal(out[0], out[1])
+    assert np.array_equal(out[1], rgb[::-1, :, ::-1])      # 24 bits: stored blue first; row 0 of a texture is the bottom row
 
 
 def test_traversal_tree_pairs_and_collapse(tmp_path):

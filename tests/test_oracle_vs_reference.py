@@ -90,13 +90,15 @@ def test_render_rows_sequential_generators():
 def test_texture_files_decode_like_the_reference(tmp_path):
     """Texture::Texture(path) (src/Texture.cpp:4-8, the reference's vendored stb_image, three channels, flipped)
     against the loaders of rtx_image.cpp / rtx_jpeg.cpp: JPEG baseline and progressive in every subsampling, with
-    restart markers, grey and CMYK; PNG in every bit depth, with palette, alpha, 16 bits and Adam7; BMP, TGA, PNM."""
+    restart markers, grey and CMYK; PNG in every bit depth, with palette, alpha, 16 bits and Adam7; TGA, PNM; BMP with
+    colour tables, channel masks and every header version; GIF (first frame, interlaced, transparent, partial frames
+    over a background colour); PSD raw and packed, 8 and 16 bits; Softimage PIC; Radiance HDR flat and run-length."""
     import image_cases
     from raytracer_amd import api
     R = binding.Reference()
     rng = np.random.default_rng(7)
     n = 0
-    for name, data in list(image_cases.jpeg_cases(rng)) + list(image_cases.lossless_cases(rng)):
+    for name, data in list(image_cases.jpeg_cases(rng)) + list(image_cases.lossless_cases(rng)) + list(image_cases.more_cases(rng)):
         path = str(tmp_path / name)
         with open(path, "wb") as f:
             f.write(data)
@@ -105,4 +107,11 @@ def test_texture_files_decode_like_the_reference(tmp_path):
         got = api.load_texture(path)
         assert got.shape == want.shape and np.array_equal(got, want), name
         n += 1
-    assert n > 120
+    assert n > 500
+    for name, data in image_cases.refused_cases(rng):
+        path = str(tmp_path / name)
+        with open(path, "wb") as f:
+            f.write(data)
+        assert R.texture_pixels(path) is None, name
+        with pytest.raises(api.RtxError):
+            api.load_texture(path)
