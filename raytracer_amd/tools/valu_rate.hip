@@ -15,10 +15,10 @@
 				 : "v"(a), "v"(b)                                                                                          \
 				 : "vcc", "s20", "s21")
 
-enum Kind { FMA, MUL, ADD, SUB, OR, ADDU, CVTUB, MAX3, MIN, MINU, CMPVCC, CMPSGPR, CNDMASK, CNDMASK_E64, PERM, LSHLOR, ANDOR, MOV, BFE, LSHLADD, ADDC, NKINDS };
+enum Kind { FMA, MUL, ADD, SUB, OR, ADDU, CVTUB, MAX3, MIN, MINU, CMPVCC, CMPSGPR, CNDMASK, CNDMASK_E64, PERM, LSHLOR, ANDOR, MOV, BFE, LSHLADD, ADDC, FMAMIX, CVTF16, NKINDS };
 const char* NAMES[NKINDS] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_or_b32", "v_add_u32", "v_cvt_f32_ubyte1", "v_max3_f32", "v_min_f32",
 							 "v_min_u32", "v_cmp_lt_f32 vcc", "v_cmp_lt_f32 sgpr", "v_cndmask_b32 vcc", "v_cndmask_b32 sgpr", "v_perm_b32", "v_lshl_or_b32",
-							 "v_and_or_b32", "v_mov_b32", "v_bfe_u32", "v_lshl_add_u32", "v_addc_co_u32"};
+							 "v_and_or_b32", "v_mov_b32", "v_bfe_u32", "v_lshl_add_u32", "v_addc_co_u32", "v_fma_mix_f32", "v_cvt_f32_f16"};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b) {
@@ -54,6 +54,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b
 							 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
 			else if (KIND == BFE) CHAIN8("v_bfe_u32", ", 3, 8");
 			else if (KIND == LSHLADD) CHAIN8("v_lshl_add_u32", ", 1, %9");
+			else if (KIND == FMAMIX) CHAIN8("v_fma_mix_f32", ", %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]");  // an f16 from the high half times an f32 plus an f32
+			else if (KIND == CVTF16) CHAIN8("v_cvt_f32_f16", "");
 			else if (KIND == ADDC)
 				asm volatile("v_addc_co_u32 %0, vcc, %0, %8, vcc\n v_addc_co_u32 %1, vcc, %1, %8, vcc\n v_addc_co_u32 %2, vcc, %2, %8, vcc\n v_addc_co_u32 %3, vcc, %3, %8, vcc\n"
 							 "v_addc_co_u32 %4, vcc, %4, %8, vcc\n v_addc_co_u32 %5, vcc, %5, %8, vcc\n v_addc_co_u32 %6, vcc, %6, %8, vcc\n v_addc_co_u32 %7, vcc, %7, %8, vcc\n"
