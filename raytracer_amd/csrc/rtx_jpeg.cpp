@@ -299,24 +299,35 @@ struct Decoder {
 // Fixed-point constants of the inverse DCT: (int)(x * 4096 + 0.5) with x a float literal.
 constexpr int fx(float x) { return (int)(x * 4096 + 0.5); }
 
+// 32-bit arithmetic that wraps: coefficients of a damaged file can overflow the fixed-point range, and the pixels
+// must then be the ones two's-complement hardware gives (the reference's plain int arithmetic in practice).
+struct Wrap {
+	uint32_t u;
+	Wrap(int v = 0) : u((uint32_t)v) {}
+	friend Wrap operator+(Wrap a, Wrap b) { Wrap r; r.u = a.u + b.u; return r; }
+	friend Wrap operator-(Wrap a, Wrap b) { Wrap r; r.u = a.u - b.u; return r; }
+	friend Wrap operator*(Wrap a, Wrap b) { Wrap r; r.u = a.u * b.u; return r; }
+	int shr(int k) const { return (int)u >> k; }  // arithmetic shift of the signed value
+};
+
 // One 8-point inverse DCT; in: s0..s7; out: the four even-part sums x0..x3 and odd-part terms t0..t3.
 struct Idct1 {
-	int x0, x1, x2, x3, t0, t1, t2, t3;
-	Idct1(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7) {
-		int p1 = (s2 + s6) * fx(0.5411961f);
-		const int e2 = p1 + s6 * fx(-1.847759065f);
-		const int e3 = p1 + s2 * fx(0.765366865f);
-		const int e0 = (s0 + s4) * 4096;
-		const int e1 = (s0 - s4) * 4096;
+	Wrap x0, x1, x2, x3, t0, t1, t2, t3;
+	Idct1(Wrap s0, Wrap s1, Wrap s2, Wrap s3, Wrap s4, Wrap s5, Wrap s6, Wrap s7) {
+		Wrap p1 = (s2 + s6) * fx(0.5411961f);
+		const Wrap e2 = p1 + s6 * fx(-1.847759065f);
+		const Wrap e3 = p1 + s2 * fx(0.765366865f);
+		const Wrap e0 = (s0 + s4) * 4096;
+		const Wrap e1 = (s0 - s4) * 4096;
 		x0 = e0 + e3;
 		x3 = e0 - e3;
 		x1 = e1 + e2;
 		x2 = e1 - e2;
-		int a0 = s7, a1 = s5, a2 = s3, a3 = s1;
-		int p3 = a0 + a2, p4 = a1 + a3;
+		Wrap a0 = s7, a1 = s5, a2 = s3, a3 = s1;
+		Wrap p3 = a0 + a2, p4 = a1 + a3;
 		p1 = a0 + a3;
-		int p2 = a1 + a2;
-		const int p5 = (p3 + p4) * fx(1.175875602f);
+		Wrap p2 = a1 + a2;
+		const Wrap p5 = (p3 + p4) * fx(1.175875602f);
 		a0 = a0 * fx(0.298631336f);
 		a1 = a1 * fx(2.053119869f);
 		a2 = a2 * fx(3.072711026f);
@@ -338,30 +349,30 @@ void idct_block(uint8_t* out, int stride, const int16_t* d) {
 	int val[64];
 	for (int i = 0; i < 8; ++i) {  // columns, two extra bits of precision kept
 		const Idct1 c(d[i], d[8 + i], d[16 + i], d[24 + i], d[32 + i], d[40 + i], d[48 + i], d[56 + i]);
-		const int x0 = c.x0 + 512, x1 = c.x1 + 512, x2 = c.x2 + 512, x3 = c.x3 + 512;
-		val[i] = (x0 + c.t3) >> 10;
-		val[56 + i] = (x0 - c.t3) >> 10;
-		val[8 + i] = (x1 + c.t2) >> 10;
-		val[48 + i] = (x1 - c.t2) >> 10;
-		val[16 + i] = (x2 + c.t1) >> 10;
-		val[40 + i] = (x2 - c.t1) >> 10;
-		val[24 + i] = (x3 + c.t0) >> 10;
-		val[32 + i] = (x3 - c.t0) >> 10;
+		const Wrap x0 = c.x0 + 512, x1 = c.x1 + 512, x2 = c.x2 + 512, x3 = c.x3 + 512;
+		val[i] = (x0 + c.t3).shr(10);
+		val[56 + i] = (x0 - c.t3).shr(10);
+		val[8 + i] = (x1 + c.t2).shr(10);
+		val[48 + i] = (x1 - c.t2).shr(10);
+		val[16 + i] = (x2 + c.t1).shr(10);
+		val[40 + i] = (x2 - c.t1).shr(10);
+		val[24 + i] = (x3 + c.t0).shr(10);
+		val[32 + i] = (x3 - c.t0).shr(10);
 	}
 	for (int i = 0; i < 8; ++i) {  // rows: remove 2^17, round, and move -128..127 to 0..255
 		const int* v = val + i * 8;
 		uint8_t* o = out + (size_t)i * stride;
 		const Idct1 c(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 		const int bias = 65536 + (128 << 17);
-		const int x0 = c.x0 + bias, x1 = c.x1 + bias, x2 = c.x2 + bias, x3 = c.x3 + bias;
-		o[0] = clamp8((x0 + c.t3) >> 17);
-		o[7] = clamp8((x0 - c.t3) >> 17);
-		o[1] = clamp8((x1 + c.t2) >> 17);
-		o[6] = clamp8((x1 - c.t2) >> 17);
-		o[2] = clamp8((x2 + c.t1) >> 17);
-		o[5] = clamp8((x2 - c.t1) >> 17);
-		o[3] = clamp8((x3 + c.t0) >> 17);
-		o[4] = clamp8((x3 - c.t0) >> 17);
+		const Wrap x0 = c.x0 + bias, x1 = c.x1 + bias, x2 = c.x2 + bias, x3 = c.x3 + bias;
+		o[0] = clamp8((x0 + c.t3).shr(17));
+		o[7] = clamp8((x0 - c.t3).shr(17));
+		o[1] = clamp8((x1 + c.t2).shr(17));
+		o[6] = clamp8((x1 - c.t2).shr(17));
+		o[2] = clamp8((x2 + c.t1).shr(17));
+		o[5] = clamp8((x2 - c.t1).shr(17));
+		o[3] = clamp8((x3 + c.t0).shr(17));
+		o[4] = clamp8((x3 - c.t0).shr(17));
 	}
 }
 
