@@ -262,10 +262,23 @@ int rtxh_tonemap(const float* accum_rgba, int frame, size_t npix, uint8_t* rgb8)
  * inputs, special[1] = byte for NaN. */
 int rtxh_tonemap_table(uint32_t* bits, uint8_t* values, int cap, int* n_out, uint8_t special[2]);
 
-/* Texture::Texture(path) (src/Texture.cpp:4-8): decodes an image file (JPEG, PNG, BMP, TGA, PPM/PGM) to 8-bit RGB,
- * bottom row first as the reference keeps it.  Writes width and height; copies the pixels when `rgb` is not
+/* Texture::Texture(path) (src/Texture.cpp:4-8): decodes an image file (JPEG, PNG, BMP, GIF, PSD, PIC, HDR, TGA,
+ * PPM/PGM: the containers of the reference's loader) to 8-bit RGB, bottom row first as the reference keeps it.  Writes width and height; copies the pixels when `rgb` is not
  * null and `capacity` >= width*height*3.  Returns the byte count needed, or a negative rtx_status. */
 long long rtxh_load_texture(const char* path, int* width, int* height, uint8_t* rgb, size_t capacity);
+
+/* RayTracer::loadModel (src/RayTracer.cpp:20-106) without its texture file, which the caller loads with
+ * rtxh_load_texture: reads a mesh (Wavefront OBJ with the Kd of its .mtl, Stanford PLY, STL, OFF; polygons fanned),
+ * places it (position * scale + origin) and fills RTX_TRIANGLE_BYTES records with the given material, the plane
+ * normal of src/RayTracer.cpp:96 and the file's vertex normals (the face normal when it has none).
+ * texture_index: the index the model's texture has in the scene, or -1; like the reference (:65-66) it is kept only
+ * when the mesh has texture coordinates, and *textured (may be null) says whether it was.  override_color: three
+ * floats or null (then the file's diffuse colour; 0.6 grey when it names none).  With triangles_out null only the
+ * triangle count is returned; otherwise `capacity` (in records) must hold it.  Returns the count or a negative
+ * rtx_status ("Can't load model in <path>", the reference's message, in rtxh_last_error). */
+long long rtxh_load_model(const char* model_path, const float origin[3], float scale, int is_metal, int is_light_emitting,
+						  int is_transparent, float specular_roughness, float refractive_index, int texture_index,
+						  const float* override_color, void* triangles_out, size_t capacity, int* textured);
 
 /* Whole drop-in: parse `config_path` with the grammar of RayTracer::parseConfigFile
  * (src/RayTracer.cpp:284-518), render on `n_devices` GPUs (device ids 0..n-1) and write

@@ -86,6 +86,7 @@ HOST_SYMBOLS = {
     "rtxh_tonemap": (_i, [_fp, _i, C.c_size_t, _vp]),
     "rtxh_tonemap_table": (_i, [_vp, _vp, _i, _ip, _vp]),
     "rtxh_load_texture": (C.c_longlong, [C.c_char_p, _ip, _ip, _vp, C.c_size_t]),
+    "rtxh_load_model": (C.c_longlong, [C.c_char_p, _fp, _f, _i, _i, _i, _f, _f, _i, _fp, _vp, C.c_size_t, _ip]),
     "rtxh_run_config": (_i, [C.c_char_p, C.c_char_p, _i]),
 }
 
@@ -195,6 +196,21 @@ def load_texture(path):
     out = np.zeros(need, np.uint8)
     _chkh(host_lib().rtxh_load_texture(os.fsencode(path), C.byref(w), C.byref(h), out.ctypes.data, need))
     return out.reshape(h.value, w.value, 3)
+
+
+def load_model(path, origin=(0.0, 0.0, 0.0), scale=1.0, is_metal=0, is_light_emitting=0, is_transparent=0, specular_roughness=0.0,
+               refractive_index=1.0, texture_index=-1, override_color=None):
+    """RayTracer::loadModel without its texture file: (triangle records as scenes.TRI_DTYPE, whether texture_index was kept)."""
+    from . import scenes
+    o = (C.c_float * 3)(*[float(x) for x in origin])
+    col = (C.c_float * 3)(*[float(x) for x in override_color]) if override_color is not None else None
+    textured = C.c_int(0)
+    args = (os.fsencode(path), o, float(scale), int(is_metal), int(is_light_emitting), int(is_transparent), float(specular_roughness),
+            float(refractive_index), int(texture_index), col)
+    n = _chkh(host_lib().rtxh_load_model(*args, None, 0, C.byref(textured)))
+    out = np.zeros(n, scenes.TRI_DTYPE)
+    _chkh(host_lib().rtxh_load_model(*args, out.ctypes.data, n, C.byref(textured)))
+    return out, bool(textured.value)
 
 
 def tonemap_table():

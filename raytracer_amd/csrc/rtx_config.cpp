@@ -304,10 +304,143 @@ bool load_ply(const std::string& path, Mesh& m) {
 	return !m.idx.empty();
 }
 
+// STL, binary or ASCII: three corners per facet, nothing shared.  The facet normal of the file goes to the three
+// corners; if any facet's is zero (many writers leave it so) the mesh counts as having none and every face gets its
+// geometric normal, like any other file without normals.
+bool load_stl(const std::string& path, Mesh& m) {
+	std::ifstream in(path, std::ios::binary);
+	if (!in) return false;
+	std::vector<char> buf((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+	if (buf.size() < 15) return false;
+	bool zeroNormal = false;
+	auto facet = [&](const float n[3], const float v[9]) {
+		const uint32_t first = (uint32_t)(m.pos.size() / 3);
+		m.pos.insert(m.pos.end(), v, v + 9);
+		for (int k = 0; k < 3; ++k) m.nrm.insert(m.nrm.end(), n, n + 3);
+		m.idx.insert(m.idx.end(), {first, first + 1, first + 2});
+		zeroNormal |= n[0] == 0.0f && n[1] == 0.0f && n[2] == 0.0f;
+	};
+	// binary: 80-byte header, facet count, 50 bytes per facet; the size settles it even if the header says "solid"
+	uint32_t count = 0;
+	if (buf.size() >= 84) std::memcpy(&count, &buf[80], 4);
+	if (buf.size() >= 84 && buf.size() == 84 + (size_t)count * 50) {
+		for (uint32_t f = 0; f < count; ++f) {
+			float rec[12];
+			std::memcpy(rec, &buf[84 + (size_t)f * 50], 48);
+			facet(rec, rec + 3);
+		}
+	}
+	else {
+		std::istringstream text(std::string(buf.begin(), buf.end()));
+		std::string tok;
+		if (!(text >> tok) || tok != "solid") return false;
+		float n[3] = {0, 0, 0}, v[9];
+		int corners = 0;
+		while (text >> tok) {
+			if (tok == "facet") {
+				text >> tok;  // "normal"
+				if (!(text >> n[0] >> n[1] >> n[2])) return false;
+				corners = 0;
+			}
+			else if (tok == "vertex") {
+				if (corners >= 3 || !(text >> v[corners * 3] >> v[corners * 3 + 1] >> v[corners * 3 + 2])) return false;
+				++corners;
+			}
+			else if (tok == "endfacet") {
+				if (corners != 3) return false;
+				facet(n, v);
+			}
+		}
+	}
+	if (zeroNormal) m.nrm.clear();
+	return !m.idx.empty();
+}
+
+// Object File Format: "OFF", counts, vertices, polygons (fanned); "#" starts a comment.  Variants with per-vertex
+// extras (COFF, NOFF, STOFF) are not read.
+bool load_off(const std::string& path, Mesh& m) {
+	std::ifstream in(path);
+	if (!in) return false;
+	std::string text, line;
+	while (std::getline(in, line)) {
+		const size_t hash = line.find('#');
+		text += line.substr(0, hash);
+		text += '\n';
+	}
+	std::istringstream ts(text);
+	std::string tag;
+	if (!(ts >> tag) || tag != "OFF") return false;
+	size_t nv = 0, nf = 0, ne = 0;
+	if (!(ts >> nv >> nf >> ne)) return false;
+	m.pos.resize(nv * 3);
+	for (float& x : m.pos)
+		if (!(ts >> x)) return false;
+	for (size_t f = 0; f < nf; ++f) {
+		size_t k = 0;
+		if (!(ts >> k)) return false;
+		std::vector<uint32_t> poly(k);
+		for (uint32_t& q : poly)
+			if (!(ts >> q) || q >= nv) return false;
+		for (size_t c = 2; c < k; ++c) m.idx.insert(m.idx.end(), {poly[0], poly[c - 1], poly[c]});
+		std::getline(ts, line);  // a colour may follow the indices
+	}
+	return !m.idx.empty();
+}
+
 bool load_mesh(const std::string& path, Mesh& m) {
 	if (ends_with(path, ".ply")) return load_ply(path, m);
 	if (ends_with(path, ".obj")) return load_obj(path, m);
-	return load_obj(path, m) || load_ply(path, m);
+	if (ends_with(path, ".stl")) return load_stl(path, m);
+	if (ends_with(path, ".off")) return load_off(path, m);
+	for (auto reader : {load_obj, load_ply, load_off, load_stl}) {
+		m = Mesh();
+		if (reader(path, m)) return true;
+	}
+	return false;
+}
+
+// The triangle records of one placed mesh (src/RayTracer.cpp:78-105), appended to `out`.
+// Done in bulk over the mesh arrays rather than corner by corner: every vertex is placed once (position * scale +
+// origin, w lane 0 * scale + origin.w, as the reference's Vector4f expression gives), the fields all triangles of
+// the model share are written into one template record, and a face then is the template plus three gathers.
+void mesh_triangles(const Mesh& mesh, const Vec4& origin, float scale, bool isMetal, bool isLightEmitting, bool isTransparent,
+					float specularRoughness, float refIndex, int32_t textureId, const std::optional<Vec4>& color,
+					std::vector<TriangleRec>& out) {
+	TriangleRec proto;
+	std::memset(&proto, 0, sizeof(proto));
+	proto.color = color ? *color : Vec4{mesh.diffuse[0], mesh.diffuse[1], mesh.diffuse[2], 0.0f};
+	proto.metal = isMetal;
+	proto.emit = isLightEmitting;
+	proto.transp = isTransparent;
+	proto.rough = specularRoughness;
+	proto.ior = refIndex;
+	proto.tex = textureId;
+
+	const size_t nVerts = mesh.pos.size() / 3;
+	std::vector<Vec4> placed(nVerts);
+	for (size_t v = 0; v < nVerts; ++v)
+		placed[v] = Vec4{mesh.pos[3 * v] * scale + origin.x, mesh.pos[3 * v + 1] * scale + origin.y, mesh.pos[3 * v + 2] * scale + origin.z,
+						 0.0f * scale + origin.w};
+
+	const bool smooth = !mesh.nrm.empty();
+	const size_t base = out.size(), nFaces = mesh.idx.size() / 3;
+	out.resize(base + nFaces, proto);
+	for (size_t f = 0; f < nFaces; ++f) {
+		TriangleRec& t = out[base + f];
+		const uint32_t* corner = &mesh.idx[3 * f];
+		for (int k = 0; k < 3; ++k) t.v[k] = placed[corner[k]];
+		t.pn = normalized(cross3(sub(t.v[1], t.v[0]), sub(t.v[2], t.v[0])));
+		for (int k = 0; k < 3; ++k) {
+			// a file without normals gets the face normal at every corner (what the importer's GenNormals step gives
+			// a flat face; for a positive scale that is the plane normal)
+			if (smooth) t.n[k] = Vec4{mesh.nrm[3 * (size_t)corner[k]], mesh.nrm[3 * (size_t)corner[k] + 1], mesh.nrm[3 * (size_t)corner[k] + 2], 0.0f};
+			else t.n[k] = t.pn;
+			if (textureId >= 0) {
+				t.uv[k][0] = mesh.uv[2 * (size_t)corner[k]];
+				t.uv[k][1] = mesh.uv[2 * (size_t)corner[k] + 1];
+			}
+		}
+	}
 }
 
 // ---- the device library, bound at run time ---------------------------------------------------
@@ -403,9 +536,6 @@ private:
 };
 
 // The model keyword of the config file (src/RayTracer.cpp:20-106): one mesh becomes triangle records.
-// Done in bulk over the mesh arrays rather than corner by corner: every vertex is placed once (position * scale +
-// origin, w lane 0 * scale + origin.w, as the reference's Vector4f expression gives), the fields all triangles of
-// the model share are written into one template record, and a face then is the template plus three gathers.
 void HostRayTracer::loadModel(const std::string& modelPath, const Vec4& origin, float scale, bool isMetal,
 							  bool isLightEmitting, bool isTransparent, float specularRoughness, float refIndex,
 							  const std::optional<std::string>& texturePath, const std::optional<Vec4>& color) {
@@ -430,41 +560,7 @@ void HostRayTracer::loadModel(const std::string& modelPath, const Vec4& origin, 
 		}
 	}
 
-	TriangleRec proto;
-	std::memset(&proto, 0, sizeof(proto));
-	proto.color = color ? *color : Vec4{mesh.diffuse[0], mesh.diffuse[1], mesh.diffuse[2], 0.0f};
-	proto.metal = isMetal;
-	proto.emit = isLightEmitting;
-	proto.transp = isTransparent;
-	proto.rough = specularRoughness;
-	proto.ior = refIndex;
-	proto.tex = textureId;
-
-	const size_t nVerts = mesh.pos.size() / 3;
-	std::vector<Vec4> placed(nVerts);
-	for (size_t v = 0; v < nVerts; ++v)
-		placed[v] = Vec4{mesh.pos[3 * v] * scale + origin.x, mesh.pos[3 * v + 1] * scale + origin.y, mesh.pos[3 * v + 2] * scale + origin.z,
-						 0.0f * scale + origin.w};
-
-	const bool smooth = !mesh.nrm.empty();
-	const size_t base = trianglesArray.size(), nFaces = mesh.idx.size() / 3;
-	trianglesArray.resize(base + nFaces, proto);
-	for (size_t f = 0; f < nFaces; ++f) {
-		TriangleRec& t = trianglesArray[base + f];
-		const uint32_t* corner = &mesh.idx[3 * f];
-		for (int k = 0; k < 3; ++k) t.v[k] = placed[corner[k]];
-		t.pn = normalized(cross3(sub(t.v[1], t.v[0]), sub(t.v[2], t.v[0])));
-		for (int k = 0; k < 3; ++k) {
-			// a file without normals gets the face normal at every corner (what the importer's GenNormals step gives
-			// a flat face; for a positive scale that is the plane normal)
-			if (smooth) t.n[k] = Vec4{mesh.nrm[3 * (size_t)corner[k]], mesh.nrm[3 * (size_t)corner[k] + 1], mesh.nrm[3 * (size_t)corner[k] + 2], 0.0f};
-			else t.n[k] = t.pn;
-			if (textureId >= 0) {
-				t.uv[k][0] = mesh.uv[2 * (size_t)corner[k]];
-				t.uv[k][1] = mesh.uv[2 * (size_t)corner[k] + 1];
-			}
-		}
-	}
+	mesh_triangles(mesh, origin, scale, isMetal, isLightEmitting, isTransparent, specularRoughness, refIndex, textureId, color, trianglesArray);
 }
 
 // src/Skybox.cpp:4-26: all six faces or none
@@ -807,6 +903,26 @@ void HostRayTracer::render(const std::string& outDir, int nDevices) {
 }  // namespace
 
 }  // namespace rtxh
+
+RTXH_API long long rtxh_load_model(const char* model_path, const float origin[3], float scale, int is_metal, int is_light_emitting,
+								   int is_transparent, float specular_roughness, float refractive_index, int texture_index,
+								   const float* override_color, void* triangles_out, size_t capacity, int* textured) {
+	if (!model_path || !origin) return rtxh::fail(RTX_ERR_ARG, "null argument");
+	rtxh::Mesh mesh;
+	if (!rtxh::load_mesh(model_path, mesh)) return rtxh::fail(RTX_ERR_STATE, std::string("Can't load model in ") + model_path);
+	const bool useTexture = texture_index >= 0 && !mesh.uv.empty();
+	if (textured) *textured = useTexture ? 1 : 0;
+	const size_t n = mesh.idx.size() / 3;
+	if (!triangles_out) return (long long)n;
+	if (capacity < n) return rtxh::fail(RTX_ERR_ARG, "triangle buffer too small");
+	std::optional<rtxh::Vec4> color;
+	if (override_color) color = rtxh::Vec4{override_color[0], override_color[1], override_color[2], 0.0f};
+	std::vector<rtxh::TriangleRec> out;
+	rtxh::mesh_triangles(mesh, rtxh::Vec4{origin[0], origin[1], origin[2], 0.0f}, scale, is_metal != 0, is_light_emitting != 0,
+						 is_transparent != 0, specular_roughness, refractive_index, useTexture ? texture_index : -1, color, out);
+	std::memcpy(triangles_out, out.data(), n * sizeof(rtxh::TriangleRec));
+	return (long long)n;
+}
 
 RTXH_API int rtxh_run_config(const char* config_path, const char* out_dir, int n_devices) {
 	if (!config_path) return rtxh::fail(RTX_ERR_ARG, "null argument");

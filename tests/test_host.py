@@ -168,6 +168,72 @@ def test_bmp_version_5_header_decodes_like_version_4(native_libs, tmp_path):
     assert np.array_equal(out[1], rgb[::-1, :, ::-1])      # 24 bits: stored blue first; row 0 of a texture is the bottom row
 
 
+def test_load_model_reads_obj_ply_stl_off_alike(native_libs, tmp_path):
+    """rtxh_load_model = RayTracer::loadModel's triangle construction (src/RayTracer.cpp:78-105) over the built-in mesh
+    readers: the same mesh written as OBJ (+ .mtl), binary PLY, binary and ASCII STL and OFF gives the records of the
+    numpy restatement bit for bit; the texture index survives only with texture coordinates; a missing file reports
+    the reference's message.  (The reference reads meshes through assimp, which has no library here: which vertices
+    an importer would merge or which normals it would generate is not pinned by this test.)"""
+    import struct
+    from test_gpu_cli import grid_mesh, load_model_py, write_obj, write_ply_binary
+    d = str(tmp_path)
+    verts, uvs, nrm, faces = grid_mesh(7, 5)
+    write_obj(os.path.join(d, "m.obj"), verts, uvs, nrm, faces)
+    with open(os.path.join(d, "m.mtl"), "w") as f:
+        f.write("newmtl a\nKd 0.25 0.5 0.75\n")
+    write_ply_binary(os.path.join(d, "m.ply"), verts, faces)
+    tri = verts[faces]                                            # (F, 3, 3)
+    up = np.array([0, 1, 0], "<f4")
+    with open(os.path.join(d, "m_bin.stl"), "wb") as f:
+        f.write(b"solid but binary".ljust(80, b" ") + struct.pack("<I", len(faces)))
+        for t in tri:
+            f.write(up.tobytes() + t.astype("<f4").tobytes() + b"\0\0")
+    with open(os.path.join(d, "m_txt.stl"), "w") as f:
+        f.write("solid grid\n")
+        for t in tri:
+            f.write(" facet normal 0 0 0\n  outer loop\n")
+            for v in t:
+                f.write("   vertex %.9g %.9g %.9g\n" % tuple(v))
+            f.write("  endloop\n endfacet\n")
+        f.write("endsolid grid\n")
+    with open(os.path.join(d, "m.off"), "w") as f:
+        f.write("OFF\n# a comment\n%d %d 0\n" % (len(verts), len(faces) // 2))
+        for v in verts:
+            f.write("%.9g %.9g %.9g\n" % tuple(v))
+        half = len(faces) // 2                                     # the grid's quads, fanned back into the same triangles
+        for (a, dd, c), (_, _, b) in zip(faces[:half], faces[half:]):
+            f.write("4 %d %d %d %d 255 0 0\n" % (a, dd, c, b))
+    mat = dict(rough=0.3, ior=1.2, metal=1, emit=0, transp=1)
+    kw = dict(origin=(0.5, -1.0, 2.0), scale=3.0, is_metal=1, is_light_emitting=0, is_transparent=1, specular_roughness=0.3, refractive_index=1.2)
+
+    def same(got, want, what):
+        for name in scenes.TRI_DTYPE.names:
+            assert np.ascontiguousarray(got[name]).tobytes() == np.ascontiguousarray(want[name]).tobytes(), (what, name)
+
+    got, textured = api.load_model(os.path.join(d, "m.obj"), texture_index=4, **kw)
+    assert textured
+    same(got, load_model_py(verts, uvs, nrm, faces, 3.0, (0.5, -1.0, 2.0), dict(mat, color=(0.25, 0.5, 0.75)), 4), "obj")
+    got, textured = api.load_model(os.path.join(d, "m.obj"), override_color=(0.9, 0.8, 0.1), **kw)
+    assert not textured
+    same(got, load_model_py(verts, uvs, nrm, faces, 3.0, (0.5, -1.0, 2.0), dict(mat, color=(0.9, 0.8, 0.1)), -1), "obj, colour given")
+    grey = dict(mat, color=(0.6, 0.6, 0.6))
+    flat = load_model_py(verts, None, None, faces, 3.0, (0.5, -1.0, 2.0), grey, -1)
+    got, textured = api.load_model(os.path.join(d, "m.ply"), texture_index=4, **kw)
+    assert not textured                                            # no texture coordinates in the file
+    same(got, flat, "ply")
+    same(api.load_model(os.path.join(d, "m_txt.stl"), **kw)[0], flat, "ascii stl, zero normals")
+    with_up = load_model_py(verts, None, np.tile(up, (len(verts), 1)), faces, 3.0, (0.5, -1.0, 2.0), grey, -1)
+    same(api.load_model(os.path.join(d, "m_bin.stl"), **kw)[0], with_up, "binary stl, facet normals")
+    quads = np.concatenate([faces[:len(faces) // 2], faces[len(faces) // 2:]], 1).reshape(-1, 3)   # a d c | a c b per quad
+    same(api.load_model(os.path.join(d, "m.off"), **kw)[0], load_model_py(verts, None, None, quads, 3.0, (0.5, -1.0, 2.0), grey, -1), "off")
+    with pytest.raises(api.RtxError, match="Can't load model in "):
+        api.load_model(os.path.join(d, "nope.obj"))
+    with open(os.path.join(d, "junk.obj"), "w") as f:
+        f.write("not a mesh\n")
+    with pytest.raises(api.RtxError, match="Can't load model in "):
+        api.load_model(os.path.join(d, "junk.obj"))
+
+
 def test_traversal_tree_pairs_and_collapse(tmp_path):
     """raytracer_amd/csrc/rtx_wide.h on the host (tests/wide_tree_check.cpp, compiled here with g++): triangles that share
     an edge and a box pair up (every quad of a displaced grid, given in the scene generator's order; nothing in a soup
