@@ -4,11 +4,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A step is one frame (one iteration of the loop at /root/reference/src/RayTracer.cpp:234: four
-samples per pixel through the whole bounce loop, accumulated) of the Sponza-class procedural atrium
-(~263k triangles, textures, cube-map sky), max_recursion_depth 4, one diffuse and one specular ray per hit:
-1920x1080 on one GPU, 3840x2160 (the multi-GPU configuration) on several.  The scene, textures and BVH are
-resident on the GPU before the timed region.  With N > 1 the image tiles are interleaved over the ranks and a step
+A frame is one iteration of the loop at /root/reference/src/RayTracer.cpp:234 (four samples per pixel through the
+whole bounce loop, accumulated) of the Sponza-class procedural atrium (~263k triangles, textures, cube-map sky),
+max_recursion_depth 4, one diffuse and one specular ray per hit: 1920x1080 on one GPU, 3840x2160 (the multi-GPU
+configuration) on several.  The scene, textures and BVH are resident on the GPU before the timed region.
+On one GPU a step is --frames-per-step consecutive frames (default 4: a quarter of the 16 frames = 64 samples per
+pixel of the 1080p configuration) handed to the library in one call, which renders them in one merged pixel batch
+-- every frame's contribution is still added to the accumulator in frame order, so each frame's image can be had
+(rtx_render_frames_tonemapped, what the command line uses); the time of single-frame calls is measured beside it
+and reported as "single_frame_calls".  With N > 1 the image tiles are interleaved over the ranks and a step
 is N consecutive frames, so every rank keeps the work of one whole frame per step (weak scaling: its 1/N tile share
 of N frames, which the library renders as one merged pixel batch); --scaling strong keeps one frame per step
 instead, and whichever of the two is not the headline is timed as well and reported under "other_scaling".
@@ -97,7 +101,9 @@ def offline_profile():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--frames-per-step", type=int, default=None,
+                    help="one GPU: frames per call of the library (default 4); several GPUs: fixed by --scaling")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=None, help="default: 1920 on one GPU, 3840 on several")
     ap.add_argument("--height", type=int, default=None, help="default: 1080 on one GPU, 2160 on several")
@@ -191,6 +197,8 @@ def main():
         counters["untraced"] += st["rays_untraced"]
 
     frames_per_step = world if (args.scaling == "weak" and args.balance == "static") else 1
+    if world == 1 and args.balance == "static":
+        frames_per_step = max(1, args.frames_per_step or 4)
 
     def step(frame, nframes):
         if args.balance == "static":
@@ -249,6 +257,10 @@ def main():
     # With several GPUs the other way of scaling is timed as well: one frame per step, every rank its 1/N tile
     # share of it (what the per-frame out_NNN.png contract of the reference costs).
     other_run = None
+    single_calls = None
+    if world == 1 and frames_per_step > 1:
+        # one frame per call, as a caller that needs the accumulator between frames would render
+        single_calls = timed_loop(1, 2, max(4, min(args.steps, 8)))
     if world > 1 and args.balance == "static":
         other_frames = 1 if frames_per_step == world else world
         other_run = timed_loop(other_frames, min(args.warmup, 2), args.steps)
@@ -288,8 +300,8 @@ def main():
             "metric": "Mrays/s (incl. secondary) at %s" % ("1080p" if (sc.width, sc.height) == (1920, 1080) else "%dx%d" % (sc.width, sc.height)),
             "value": round(rays_total / dt / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak" if frames_per_step == world else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "atrium (Sponza-class, %d triangles, %d textures + cube-map sky) %dx%d, 4 spp per step, "
+            "higher_is_better": True, "scaling": "weak" if (frames_per_step == world or world == 1) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "atrium (Sponza-class, %d triangles, %d textures + cube-map sky) %dx%d, 4 spp per frame, "
                                    "max_recursion_depth %d, diffuse 1, specular 1" % (len(sc.tris), len(sc.textures), sc.width, sc.height, sc.max_depth),
                        "frames_per_step": frames_per_step,
                        "backend": "rccl" if backend == "nccl" else backend,
@@ -302,6 +314,12 @@ def main():
             "traversed_Mrays_per_s": round((rays_total - main_run["untraced"]) / dt / 1e6, 2),
             "gpu_kernel_ms_per_step": {"trace": round(trace_ms_sum / args.steps / world, 3), "shade_gather_accumulate": round(shade_ms_sum / args.steps / world, 3)},
         }
+        if world == 1:
+            out["ms_per_frame"] = round(dt / args.steps / frames_per_step * 1e3, 3)
+        if single_calls is not None:
+            steps1 = max(4, min(args.steps, 8))
+            out["single_frame_calls"] = {"ms_per_frame": round(single_calls["dt"] / steps1 * 1e3, 3),
+                                         "value": round(single_calls["rays"] / single_calls["dt"] / 1e6, 2), "unit": "Mrays/s"}
         if single_rank is not None:
             out["single_rank_same_workload"] = single_rank
         if other_run is not None:

@@ -138,8 +138,9 @@ int rtx_accum_reset(rtx_scene* s);
  * (1-based like `i` at src/RayTracer.cpp:234): camera rays, traversal, intersection, bounce
  * loop, accumulateImg(row,col) += sum*0.25f (src/RayTracer.cpp:237-246).  The tone map is
  * rtx_tonemap_read (or the caller's own); the PNG write stays with the caller.
- * With n_frames > 1 the frames of a small tile share are rendered together in merged pixel batches; every
- * pixel still receives its frames in ascending order, so the accumulator equals that of n_frames calls. */
+ * With n_frames > 1 the frames are rendered together in merged pixel batches (up to four 1920x1080 frames' worth
+ * of pixels per batch, the work arena permitting); every pixel still receives its frames in ascending order, so
+ * the accumulator equals that of n_frames calls. */
 int rtx_render_frames(rtx_scene* s, uint32_t first_frame, uint32_t n_frames);
 
 /* Copies the accumulator to host memory: height*width*4 floats. */
@@ -158,6 +159,13 @@ int rtx_scene_set_tonemap_table(rtx_scene* s, const uint32_t* bits, const uint8_
 /* Tone-maps the accumulator after `frame` frames and copies height*width*3 bytes (RGB, row-major, the
  * outputBuffer of src/RayTracer.cpp:257) to host memory. */
 int rtx_tonemap_read(rtx_scene* s, int frame, uint8_t* host_rgb8);
+/* rtx_render_frames and, for every frame of the call, the image rtx_tonemap_read would give right after that frame
+ * (the out_%03d.png of src/RayTracer.cpp:263-269): host_rgb8[k], k = 0..n_frames-1, receives height*width*3 bytes
+ * for frame first_frame + k.  The frames still share merged pixel batches -- their queues are filled together, which
+ * is what makes several frames cheaper than as many single calls -- and each frame's contribution is added to the
+ * accumulator in frame order, with the tone map and the copy of frame k enqueued between the additions of frames k
+ * and k + 1.  Needs rtx_scene_set_tonemap_table; page-locked arrays (rtx_host_alloc) are copied at link speed. */
+int rtx_render_frames_tonemapped(rtx_scene* s, uint32_t first_frame, uint32_t n_frames, uint8_t* const* host_rgb8);
 
 /* Closest hit of every primary ray (the head of RayTracer::color, src/RayTracer.cpp:137-151,
  * applied to Camera::getRay, src/Camera.cpp:40-49): tri_ids[height*width*4] (reference triangle

@@ -63,6 +63,7 @@ HIP_SYMBOLS = {
     "rtx_accum_write": (_i, [_vp, _fp]),
     "rtx_scene_set_tonemap_table": (_i, [_vp, _vp, _vp, _i, C.c_uint8, C.c_uint8]),
     "rtx_tonemap_read": (_i, [_vp, _i, _vp]),
+    "rtx_render_frames_tonemapped": (_i, [_vp, _u32, _u32, _vp]),
     "rtx_primary_hits": (_i, [_vp, _i, _ip, _fp]),
     "rtx_host_alloc": (_vp, [C.c_size_t]),
     "rtx_host_free": (_i, [_vp]),
@@ -345,6 +346,21 @@ class RayTracer:
     def accum(self):
         out = np.zeros((self.height, self.width, 4), np.float32)
         _chk(self.lib.rtx_accum_read(self.h, _p(out.reshape(-1))))
+        return out
+
+    def _set_tone_table(self):
+        if not getattr(self, "_tone_set", False):
+            bits, vals, neg, nan = tonemap_table()
+            _chk(self.lib.rtx_scene_set_tonemap_table(self.h, bits.ctypes.data, vals.ctypes.data, len(bits), neg, nan))
+            self._tone_set = True
+
+    def render_images(self, first_frame=1, n_frames=1):
+        """Frames first_frame .. first_frame + n_frames - 1 in merged pixel batches, and the 8-bit image after each of
+        them: (n_frames, H, W, 3) uint8."""
+        self._set_tone_table()
+        out = np.zeros((n_frames, self.height, self.width, 3), np.uint8)
+        ptrs = (C.c_void_p * n_frames)(*[out[k].ctypes.data for k in range(n_frames)])
+        _chk(self.lib.rtx_render_frames_tonemapped(self.h, first_frame, n_frames, C.cast(ptrs, C.c_void_p)))
         return out
 
     def tonemap_read(self, frame):

@@ -181,7 +181,10 @@ struct rtx_scene {
 	                                 // the last set of blocks is a full one (four per CU: a third of the chip works through the last quarter)
 	int tailLanes = 2;               // a wave down to this many rays after the queue's end hands them over at once (RTX_TAIL_LANES)
 	int tailVisits = 32;             // the same allowance for rays still in flight once a wave finds the queue exhausted (RTX_TAIL_VISITS)
-	long long mergeBlocks = 131072;  // frames of a multi-frame call share a batch up to this many 4x4-pixel blocks (RTX_MERGE_BLOCKS)
+	long long mergeBlocks = 524288;  // frames of a multi-frame call share a batch up to this many 4x4-pixel blocks (RTX_MERGE_BLOCKS): four 1080p frames or one
+	                                 // 3840x2160 frame; every level's launch ends with its waves draining their last rays, about 0.25 ms whatever the queue holds
+	uint8_t* const* toneOut = nullptr;  // rtx_render_frames_tonemapped: where the 8-bit image after frame toneOutFirst + k goes (host memory), k < toneOutCount
+	uint32_t toneOutFirst = 0, toneOutCount = 0;
 	int traceRefill = TRACE_REFILL, traceChunk = TRACE_CHUNK, traceBlocksPerCU = 6, traceTriBatch = 28;  // tunables (RTX_TRACE_* env)
 	hipStream_t stream = nullptr;
 	hipStream_t ownStream = nullptr;
@@ -891,6 +894,17 @@ int render_range(rtx_scene* s, const DevScene& d, uint32_t frame, const RenderTa
 				const int npix = seg.nSamples / 4;
 				hipLaunchKernelGGL(k_accumulate, dim3((npix + 255) / 256), dim3(256), 0, s->stream, d, seg,
 								   (const float4*)(A[0] + (size_t)(segBegin - g0) * SAMPLES_PER_BLOCK), s->dAccum, s->dCounts.p);
+				// The frame's last blocks: the accumulator now is the image after that frame, which the caller may have
+				// asked for (the frames behind it in this batch are added only after the copy, in stream order).  A batch
+				// that overflowed a queue stores nothing and is rendered again: its images are then written a second time.
+				const long long frameNo = (long long)frame + f;
+				if (s->toneOut && segEnd == (f + 1) * blocksPerFrame && frameNo >= s->toneOutFirst && frameNo < (long long)s->toneOutFirst + s->toneOutCount) {
+					const size_t npixAll = (size_t)s->width * s->height;
+					hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((npixAll + 1023) / 1024)), dim3(256), 0, s->stream, s->dAccum, (int)npixAll, (float)frameNo,
+									   s->dToneBits.p, s->dToneVal.p, s->toneN, s->toneNeg, s->toneNan, s->dRgb8.p);
+					RTX_LAUNCHED("k_tonemap");
+					HIPCHK(hipMemcpyAsync(s->toneOut[frameNo - s->toneOutFirst], s->dRgb8.p, npixAll * 3, hipMemcpyDeviceToHost, s->stream));
+				}
 			}
 		}
 		else
@@ -1500,8 +1514,9 @@ RTX_API int rtx_accum_reset(rtx_scene* s) {
 	return RTX_OK;
 }
 
-RTX_API int rtx_render_frames(rtx_scene* s, uint32_t first_frame, uint32_t n_frames) {
-	if (!s) return fail(RTX_ERR_ARG, "scene is null");
+namespace {
+
+int render_frames_call(rtx_scene* s, uint32_t first_frame, uint32_t n_frames) {
 	int rc = ensure_ready(s, true);
 	if (rc) return rc;
 	rc = begin_call(s);
@@ -1540,6 +1555,32 @@ RTX_API int rtx_render_frames(rtx_scene* s, uint32_t first_frame, uint32_t n_fra
 		for (int k = 0, n = tile_slots(s); k < n; ++k) s->tileLog[(size_t)(s->tileFirst + k * s->tileStride)] = 1;
 	}
 	return finish_stats(s);
+}
+
+}  // namespace
+
+RTX_API int rtx_render_frames(rtx_scene* s, uint32_t first_frame, uint32_t n_frames) {
+	if (!s) return fail(RTX_ERR_ARG, "scene is null");
+	return render_frames_call(s, first_frame, n_frames);
+}
+
+RTX_API int rtx_render_frames_tonemapped(rtx_scene* s, uint32_t first_frame, uint32_t n_frames, uint8_t* const* host_rgb8) {
+	if (!s || !host_rgb8) return fail(RTX_ERR_ARG, "null argument");
+	if (first_frame < 1) return fail(RTX_ERR_ARG, "frame must be >= 1");
+	for (uint32_t k = 0; k < n_frames; ++k)
+		if (!host_rgb8[k]) return fail(RTX_ERR_ARG, "null image pointer");
+	if (!s->toneN) return fail(RTX_ERR_STATE, "rtx_scene_set_tonemap_table has not been called");
+	int rc = ensure_ready(s, true);
+	if (rc) return rc;
+	const size_t npix = (size_t)s->width * s->height;
+	if (!s->dRgb8.p || s->dRgb8.n < npix * 3 + 16) HIPCHK(s->dRgb8.alloc(npix * 3 + 16));
+	s->toneOut = host_rgb8;
+	s->toneOutFirst = first_frame;
+	s->toneOutCount = n_frames;
+	rc = render_frames_call(s, first_frame, n_frames);
+	s->toneOut = nullptr;
+	s->toneOutCount = 0;
+	return rc;
 }
 
 RTX_API int rtx_accum_read(rtx_scene* s, float* host_rgba) {

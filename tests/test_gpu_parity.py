@@ -894,6 +894,47 @@ def test_device_tonemap_equals_host(libs):
         assert got[0, 4, 0] == 255
 
 
+def test_frames_of_a_merged_batch_each_give_their_image(libs):
+    """rtx_render_frames_tonemapped: five frames rendered in merged pixel batches hand back, frame by frame, the bytes
+    that one frame per call followed by rtx_tonemap_read gives (the out_NNN.png sequence of src/RayTracer.cpp:263-269),
+    and leave the same accumulator -- with every frame in one batch, and with an arena so small that the batches cut
+    frames apart."""
+    sc = scenes.mixed_scene(seed=8, width=200, height=136)
+    rt = gpu_scene(sc)
+    rt.reset()
+    want = []
+    for frame in range(1, 6):
+        rt.render(frame, 1)
+        want.append(rt.tonemap_read(frame))
+    acc_want = rt.accum()
+    assert any(not np.array_equal(want[0], w) for w in want[1:])         # the frames do differ
+    for arena in (0, 24 << 20):
+        rt.set_arena_bytes(arena)
+        rt.reset()
+        got = rt.render_images(1, 5)
+        batches = rt.stats()["chunks"]
+        assert batches == 1 if arena == 0 else batches > 5, batches
+        for k in range(5):
+            assert np.array_equal(got[k], want[k]), "frame %d, arena %d" % (k + 1, arena)
+        assert np.array_equal(rt.accum().view(np.uint32), acc_want.view(np.uint32))
+    rt.set_arena_bytes(0)
+    # the images of a later group continue the sequence
+    got = rt.render_images(6, 2)
+    rt.render(8, 1)
+    acc8 = rt.accum()
+    rt.reset()
+    for frame in range(1, 8):
+        rt.render(frame, 1)
+        if frame >= 6:
+            assert np.array_equal(rt.tonemap_read(frame), got[frame - 6])
+    rt.render(8, 1)
+    assert np.array_equal(rt.accum().view(np.uint32), acc8.view(np.uint32))
+    lib = api.hip_lib()
+    assert lib.rtx_render_frames_tonemapped(rt.h, 0, 1, None) == -1
+    ptrs = (C.c_void_p * 2)(got[0].ctypes.data, None)
+    assert lib.rtx_render_frames_tonemapped(rt.h, 1, 2, C.cast(ptrs, C.c_void_p)) == -1 and b"null image" in lib.rtx_last_error()
+
+
 def test_error_paths(libs):
     lib = api.hip_lib()
     h = C.c_void_p()
