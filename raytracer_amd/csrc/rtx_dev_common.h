@@ -37,8 +37,9 @@ struct DevScene {
 	const float4* triHit;    // 4 x float4 per triangle in candidate-rank order: n, v0, v1, v2, index
 	const float4* triWide;   // the same records in the order of the wide tree's leaves (a leaf's two triangles side by
 	                         // side), fourth quad: index, rank, -, -
-	const float4* triShade;  // 8 x float4 (one 128-byte line) per triangle in candidate-rank order:
-	                         // n0 r | n1 g | n2 b | rough ior tex flags | uv0 uv1 | uv2 - - | - | -
+	const float4* triShade;  // 4 x float4 per triangle in candidate-rank order: n0 uv0.x | n1 uv0.y | n2 uv1.x | uv1.y uv2.x uv2.y material
+	const float4* mats;      // 2 x float4 per material (the distinct colour / roughness / index / texture / flags of the triangles):
+	                         // r g b roughness | refractive index, texture id, flags, -
 	const uint8_t* texels;
 	const int4* texDesc;     // byte offset, width, height
 	const float* cosT;
@@ -53,14 +54,14 @@ struct DevScene {
 	uint32_t seedKey;
 	float sceneAbsMax;
 	int tilesX;
-	int nWide, nTris, nTex;  // record counts of `wide`, of the triangle arrays and of texDesc
+	int nWide, nTris, nTex, nMats;  // record counts of `wide`, of the triangle arrays, of texDesc and of mats
 	unsigned* fault;         // one word: a kernel that meets an index outside those counts sets a bit and skips
 };
 
 // Bits of DevScene::fault.  An index is checked wherever it comes out of a queue record and is about to address
 // scene data: a record nobody wrote must end in an error code, never in an access outside the arrays.
 constexpr unsigned FAULT_HIT_RANK = 1u, FAULT_TEX_ID = 2u, FAULT_CHILD_SLOT = 4u, FAULT_NODE = 8u, FAULT_LEAF = 16u,
-				   FAULT_STACK = 32u, FAULT_LONG_ROUNDS = 64u, FAULT_LIST_ENTRY = 128u;
+				   FAULT_STACK = 32u, FAULT_LONG_ROUNDS = 64u, FAULT_LIST_ENTRY = 128u, FAULT_MATERIAL = 256u;
 
 // ------------------------------------------------------------------------------------------------
 // Small device helpers.  dot4 is Eigen's reduction order with the (zero) w lane kept as "+ 0.0f".
@@ -93,6 +94,7 @@ __device__ __forceinline__ float clamp01(float u) {
 // the first LDS_TEX textures.  Every look-up in them is a scattered access of a whole wave; in LDS it costs no trip to
 // the vector-memory path, which the shading kernels are bound by.
 constexpr int LDS_TEX = 64;
+constexpr int LDS_MATS = 128;  // materials the shade kernel keeps in LDS (4 KB); a scene with more reads the others from global memory
 struct LdsTables {
 	const float* gamma;   // 256 floats
 	const int4* desc;     // LDS_TEX descriptors: those of the first min(nTex, LDS_TEX) textures, then the six sky faces' at LDS_SKY

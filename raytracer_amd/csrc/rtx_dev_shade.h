@@ -75,7 +75,9 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 	__shared__ float2 s_cs[512];  // (cos, sin) of the reference's 512-entry tables
 	__shared__ float s_gamma[256];
 	__shared__ int4 s_desc[LDS_TEX + 6];
+	__shared__ float4 s_mat[2 * LDS_MATS];
 	for (int i = threadIdx.x; i < 512; i += SHADE_THREADS) s_cs[i] = make_float2(sc.cosT[i], sc.sinT[i]);
+	for (int i = threadIdx.x; i < 2 * LDS_MATS; i += SHADE_THREADS) s_mat[i] = i < 2 * sc.nMats ? sc.mats[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	lds_tables_fill(sc, s_gamma, s_desc, SHADE_THREADS);
 	const LdsTables lt{s_gamma, s_desc};
 	unsigned deadAll = 0, shadedAll = 0, fetchAll = 0;  // thread 0: the block's counts over all its rounds
@@ -120,16 +122,26 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 			else if (level < sc.maxDepth) {
 				// (at level == maxDepth every hit returns zero, src/RayTracer.cpp:170; the any-hit
 				//  traversal reports such hits with rank 0, which is never dereferenced)
-				// one aligned 64-byte record serves every hit; the texture coordinates live apart
-				const float4* T = sc.triShade + (size_t)rank * 8;
-				float4 s0 = T[0], s1 = T[1], s2 = T[2], s3 = T[3];
-				// the texture coordinates lie in the same 128-byte line and are asked for with it: loaded where they are
-				// used, behind the material tests, they would cost a second round trip
-				const float4 u01 = T[4], u2 = T[5];
-				asm volatile("" : : "v"(u01.x), "v"(u01.y), "v"(u01.z), "v"(u01.w), "v"(u2.x), "v"(u2.y));
+				// one aligned 64-byte record per hit: the vertex normals, the texture coordinates and the number of the
+				// triangle's material; the materials themselves (colour, roughness, index, texture, flags: what triangles
+				// of one model share) are a small table, the first LDS_MATS of which the block keeps in LDS
+				const float4* T = sc.triShade + (size_t)rank * 4;
+				const float4 s0 = T[0], s1 = T[1], s2 = T[2], s3 = T[3];
+				int matId = __float_as_int(s3.w);
+				if ((unsigned)matId >= (unsigned)sc.nMats) {
+					atomicOr(sc.fault, FAULT_MATERIAL);  // not a record of this scene: treated as the first material, reported to the host
+					matId = 0;
+				}
+				float4 m0 = s_mat[2 * min(matId, LDS_MATS - 1)], m1 = s_mat[2 * min(matId, LDS_MATS - 1) + 1];
+				if (matId >= LDS_MATS) {
+					// (the empty asm keeps the two look-ups apart: merged, they become one slow load through an address of either kind)
+					m0 = sc.mats[2 * (size_t)matId];
+					m1 = sc.mats[2 * (size_t)matId + 1];
+					asm volatile("" : "+v"(m0.x), "+v"(m0.y), "+v"(m0.z), "+v"(m0.w), "+v"(m1.x), "+v"(m1.y), "+v"(m1.z));
+				}
 				const float t = H.y, alpha = H.z, beta = H.w;
-				const int triFlags = __float_as_int(s3.w);
-				const int texId = __float_as_int(s3.z);
+				const int triFlags = __float_as_int(m1.z);
+				const int texId = __float_as_int(m1.y);
 				hx = O.x + t * dx;
 				hy = O.y + t * dy;
 				hz = O.z + t * dz;
@@ -150,13 +162,13 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 					// back side: zero
 				}
 				else if (triFlags & TRI_EMIT) {
-					val = make_float3(s0.w, s1.w, s2.w);
+					val = make_float3(m0.x, m0.y, m0.z);
 				}
 				else {
 					shaded = 1;
-					val = make_float3(s0.w, s1.w, s2.w);  // colour, consumed by k_gather
-					rough = s3.x;
-					ior = s3.y;
+					val = make_float3(m0.x, m0.y, m0.z);  // colour, consumed by k_gather
+					rough = m0.w;
+					ior = m1.x;
 					if (triFlags & TRI_METAL) {
 						kind = KIND_METAL;
 						nchild = S;
@@ -172,8 +184,8 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, int level,
 						if (texId >= sc.nTex) atomicOr(sc.fault, FAULT_TEX_ID);
 						else if (texId >= 0) {
 							flags |= FLAG_TEX;
-							float u = (alpha * u01.x + beta * u01.z) + g * u2.x;
-							float v = (alpha * u01.y + beta * u01.w) + g * u2.y;
+							float u = (alpha * s0.w + beta * s2.w) + g * s3.y;
+							float v = (alpha * s1.w + beta * s3.x) + g * s3.z;
 							texel = tex_fetch_rgb(sc, lt, texId, u, v);
 							fetches = 1;
 						}

@@ -51,6 +51,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/rtx.h"
@@ -226,7 +227,7 @@ struct rtx_scene {
 	uint32_t numWide = 0;
 	uint32_t numPairs = 0;
 	// device
-	DevBuf<float4> dPairs, dWide, dTriHit, dTriWide, dTriShade;
+	DevBuf<float4> dPairs, dWide, dTriHit, dTriWide, dTriShade, dMats;
 	DevBuf<unsigned> dToneBits;
 	DevBuf<unsigned char> dToneVal, dRgb8;
 	int toneN = 0;
@@ -264,7 +265,7 @@ struct rtx_scene {
 
 	~rtx_scene() {
 		(void)hipSetDevice(device);
-		dPairs.release(); dWide.release(); dTriHit.release(); dTriWide.release(); dTriShade.release(); dToneBits.release(); dToneVal.release(); dRgb8.release(); dTexels.release(); dTexDesc.release();
+		dPairs.release(); dWide.release(); dTriHit.release(); dTriWide.release(); dTriShade.release(); dMats.release(); dToneBits.release(); dToneVal.release(); dRgb8.release(); dTexels.release(); dTexDesc.release();
 		dTables.release(); dAccumOwn.release(); dTilePack.release(); dTileRecv.release(); arena.release(); dCounts.release(); dStats.release();
 		if (hCounts) (void)hipHostFree(hCounts);
 		if (hStats) (void)hipHostFree(hStats);
@@ -332,6 +333,8 @@ DevScene make_dev_scene(const rtx_scene* s) {
 	d.triHit = s->dTriHit.p;
 	d.triWide = s->dTriWide.p;
 	d.triShade = s->dTriShade.p;
+	d.mats = s->dMats.p;
+	d.nMats = (int)(s->dMats.n / 2);
 	d.texels = s->dTexels.p;
 	d.texDesc = s->dTexDesc.p;
 	d.cosT = s->dTables.p;
@@ -1374,7 +1377,23 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 
 	lap("-");
 	// Triangle records in rank order.
-	std::vector<float4> th((size_t)std::max<uint32_t>(ntri, 1) * 4), ts((size_t)std::max<uint32_t>(ntri, 1) * 8);
+	// Shading records: normals, texture coordinates and the number of the triangle's material.  What the triangles of
+	// a model share (src/RayTracer.cpp:76-103 copies it into every Triangle) -- colour, roughness, refractive index,
+	// texture, the three flags -- is kept once per distinct combination, compared bit for bit.
+	std::vector<float4> th((size_t)std::max<uint32_t>(ntri, 1) * 4), ts((size_t)std::max<uint32_t>(ntri, 1) * 4);
+	std::vector<float4> mats;
+	struct MatKey {
+		uint32_t w[7];
+		bool operator==(const MatKey& o) const { return std::memcmp(w, o.w, sizeof(w)) == 0; }
+	};
+	struct MatHash {
+		size_t operator()(const MatKey& k) const {
+			uint64_t h = 0xCBF29CE484222325ull;
+			for (uint32_t v : k.w) h = (h ^ v) * 0x100000001B3ull;
+			return (size_t)h;
+		}
+	};
+	std::unordered_map<MatKey, int, MatHash> matIndex;
 	for (uint32_t i = 0; i < ntri; ++i) {
 		const HostTri& t = s->tris[i];
 		const size_t r = (size_t)rankOf[i];
@@ -1397,12 +1416,32 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 		float texf, flagf;
 		std::memcpy(&texf, &t.tex, 4);
 		std::memcpy(&flagf, &flags, 4);
-		ts[r * 8 + 0] = make_float4(t.n[0][0], t.n[0][1], t.n[0][2], t.color[0]);
-		ts[r * 8 + 1] = make_float4(t.n[1][0], t.n[1][1], t.n[1][2], t.color[1]);
-		ts[r * 8 + 2] = make_float4(t.n[2][0], t.n[2][1], t.n[2][2], t.color[2]);
-		ts[r * 8 + 3] = make_float4(t.rough, t.ior, texf, flagf);
-		ts[r * 8 + 4] = make_float4(t.uv[0][0], t.uv[0][1], t.uv[1][0], t.uv[1][1]);
-		ts[r * 8 + 5] = make_float4(t.uv[2][0], t.uv[2][1], 0.0f, 0.0f);
+		MatKey mk;
+		std::memcpy(&mk.w[0], t.color, 12);
+		std::memcpy(&mk.w[3], &t.rough, 4);
+		std::memcpy(&mk.w[4], &t.ior, 4);
+		mk.w[5] = (uint32_t)t.tex;
+		mk.w[6] = (uint32_t)flags;
+		auto found = matIndex.find(mk);
+		if (found == matIndex.end()) {
+			found = matIndex.emplace(mk, (int)(mats.size() / 2)).first;
+			mats.push_back(make_float4(t.color[0], t.color[1], t.color[2], t.rough));
+			mats.push_back(make_float4(t.ior, texf, flagf, 0.0f));
+		}
+		float matf;
+		const int32_t matId = found->second;
+		std::memcpy(&matf, &matId, 4);
+		ts[r * 4 + 0] = make_float4(t.n[0][0], t.n[0][1], t.n[0][2], t.uv[0][0]);
+		ts[r * 4 + 1] = make_float4(t.n[1][0], t.n[1][1], t.n[1][2], t.uv[0][1]);
+		ts[r * 4 + 2] = make_float4(t.n[2][0], t.n[2][1], t.n[2][2], t.uv[1][0]);
+		ts[r * 4 + 3] = make_float4(t.uv[1][1], t.uv[2][0], t.uv[2][1], matf);
+	}
+	if (mats.empty()) {  // a scene without triangles still has a table to point at
+		float noTex;
+		const int32_t minusOne = -1;
+		std::memcpy(&noTex, &minusOne, 4);
+		mats.push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+		mats.push_back(make_float4(1.0f, noTex, 0.0f, 0.0f));
 	}
 
 	// The same hit records once more in the order of the wide tree's leaves (the two triangles of a leaf side by
@@ -1438,6 +1477,8 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 	HIPCHK(hipMemcpy(s->dTriHit.p, th.data(), th.size() * sizeof(float4), hipMemcpyHostToDevice));
 	HIPCHK(s->dTriShade.alloc(ts.size()));
 	HIPCHK(hipMemcpy(s->dTriShade.p, ts.data(), ts.size() * sizeof(float4), hipMemcpyHostToDevice));
+	HIPCHK(s->dMats.alloc(mats.size()));
+	HIPCHK(hipMemcpy(s->dMats.p, mats.data(), mats.size() * sizeof(float4), hipMemcpyHostToDevice));
 	lap("copies to the device");
 	s->rankOf.swap(rankOf);
 	s->numPairs = (uint32_t)npairs;
