@@ -63,6 +63,43 @@ __device__ __forceinline__ bool tri_test_vals(float nx, float ny, float nz, floa
 	return true;
 }
 
+// The same test for a record of the wide tree's leaves, which carries the part of the elimination that does not depend
+// on the ray.  Columns 0 and 1 of the rows (a1_i, a2_i, b_i) are the triangle's own, so both pivot choices, the
+// quotient p1 / p0 of the first pivot row and the second pivot e1 are known when the record is written (host side of
+// rtx_scene_set_bvh, same operations in the same order: IEEE division, one fused multiply-add); what remains per ray
+// is column 2: b of the first pivot's row over p0, one fused multiply-add into the second pivot's row, its division
+// by e1, and the back-substitution -- the values src/Triangle.cpp:61-82 computes, bit for bit.
+// bits: axis (0 x, 1 y, 2 z) of the first pivot's row in bits 0-1, of the second pivot's row in bits 2-3.
+__device__ __forceinline__ bool tri_test_pre(float nx, float ny, float nz, float v0x, float v0y, float v0z, float v2x, float v2y,
+											 float v2z, int rank, int bits, float p1q, float e1, float ox, float oy, float oz,
+											 float dx, float dy, float dz, HitState& best) {
+	float temp = dot3w(nx, ny, nz, v0x - ox, v0y - oy, v0z - oz);
+	float t = temp / dot3w(nx, ny, nz, dx, dy, dz);
+	if (!(t > 0.001f)) return false;
+	if (t > best.t || (t == best.t && rank > best.rank)) return false;
+	const float bx = (ox + t * dx) - v2x;
+	const float by = (oy + t * dy) - v2y;
+	const float bz = (oz + t * dz) - v2z;
+	const float cx = v0x - v2x, cy = v0y - v2y, cz = v0z - v2z;  // column 0: a1 = v0 - v2 (src/Triangle.cpp:31)
+	const int ax0 = bits & 3, ax1 = (bits >> 2) & 3;
+	const float p0 = ax0 == 2 ? cz : (ax0 == 1 ? cy : cx);
+	const float bp = ax0 == 2 ? bz : (ax0 == 1 ? by : bx);
+	const float e0 = ax1 == 2 ? cz : (ax1 == 1 ? cy : cx);
+	const float be = ax1 == 2 ? bz : (ax1 == 1 ? by : bx);
+	const float p2 = bp / p0;
+	float e2 = __fmaf_rn(-p2, e0, be);
+	e2 = e2 / e1;
+	const float alpha = __fmaf_rn(-e2, p1q, p2);
+	const float beta = e2;
+	const bool accept = (0.0f <= alpha) & (alpha <= 1.0f) & (0.0f <= beta) & (beta <= 1.0f) & (alpha + beta <= 1.0f);
+	if (!accept) return false;
+	best.t = t;
+	best.alpha = alpha;
+	best.beta = beta;
+	best.rank = rank;
+	return true;
+}
+
 // The triangle stored at `rank`: q0 = n.xyz v0.x | q1 = v0.yz v1.xy | q2 = v1.z v2.xyz | q3 = id - - -
 __device__ __forceinline__ bool tri_test(const float4* __restrict__ triHit, int rank, float ox, float oy, float oz,
 										 float dx, float dy, float dz, HitState& best) {
@@ -368,10 +405,13 @@ template <bool STATS>
 __device__ __forceinline__ int wide_leaf_test(const float4* __restrict__ T, const RaySlab& r, float dx, float dy, float dz, HitState& best,
 											  unsigned& boxTests, unsigned& triTests) {
 	const float4 q0 = T[0], q1 = T[1], q2 = T[2];
-	const int rank = __float_as_int(T[3].y);
+	// fourth quad: index | rank << 4 | pivot rows | p1 / p0 | second pivot (see tri_test_pre)
+	const int rankBits = __float_as_int(T[3].y);
+	const float p1q = T[3].z, e1 = T[3].w;
+	const int rank = rankBits >> 4;
 	// all of the record is asked for at once: left to itself the compiler moves the loads of the plane normal and of the
 	// rank behind the box test, where they cost further memory round trips in every leaf phase (2 to 5 % of a launch)
-	asm volatile("" : : "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(rank));
+	asm volatile("" : : "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(rankBits), "v"(p1q), "v"(e1));
 	const float v0x = q0.w, v0y = q1.x, v0z = q1.y, v1x = q1.z, v1y = q1.w, v1z = q2.x, v2x = q2.y, v2y = q2.z, v2z = q2.w;
 	const float lx = fminf(fminf(v0x, v1x), v2x), hx = fmaxf(fmaxf(v0x, v1x), v2x);
 	const float ly = fminf(fminf(v0y, v1y), v2y), hy = fmaxf(fmaxf(v0y, v1y), v2y);
@@ -385,7 +425,7 @@ __device__ __forceinline__ int wide_leaf_test(const float4* __restrict__ T, cons
 	if ((t0x != t0x || t1x != t1x) && tmax < tmin) return 2;
 	if (tmax < tmin) return 0;
 	if (STATS) triTests++;
-	return tri_test_vals(q0.x, q0.y, q0.z, v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z, rank, r.ox, r.oy, r.oz, dx, dy, dz, best) ? 1 : 0;
+	return tri_test_pre(q0.x, q0.y, q0.z, v0x, v0y, v0z, v2x, v2y, v2z, rank, rankBits & 15, p1q, e1, r.ox, r.oy, r.oz, dx, dy, dz, best) ? 1 : 0;
 }
 
 template <int STACK, bool ANYHIT, bool STATS>

@@ -1141,7 +1141,7 @@ RTX_API int rtx_scene_set_camera(rtx_scene* s, const float origin[4], const floa
 
 RTX_API int rtx_scene_set_triangles(rtx_scene* s, const void* triangles, uint32_t n) {
 	if (!s || (!triangles && n)) return fail(RTX_ERR_ARG, "null argument");
-	if (n > (1u << 30)) return fail(RTX_ERR_ARG, "too many triangles");
+	if (n > (1u << 27)) return fail(RTX_ERR_ARG, "too many triangles");  // a leaf record keeps its triangle's rank in 28 bits
 	s->tris.resize(n);
 	if (n) std::memcpy((void*)s->tris.data(), triangles, (size_t)n * sizeof(HostTri));
 	float amax = 0.0f;
@@ -1454,10 +1454,32 @@ RTX_API int rtx_scene_set_bvh(rtx_scene* s, const void* linear_nodes, uint32_t n
 			tw[rec * 4 + 0] = th[r * 4 + 0];
 			tw[rec * 4 + 1] = th[r * 4 + 1];
 			tw[rec * 4 + 2] = th[r * 4 + 2];
+			// The part of Triangle::hit's elimination (src/Triangle.cpp:41-79) that does not depend on the ray, with the
+			// reference's operations in the reference's order: rows (a1_i, a2_i), first pivot = largest |a1_i| (strict >,
+			// rows tried in order), its row divided by the pivot, the other two rows reduced by one fused multiply-add,
+			// second pivot = the larger |column 1| of those (strict >).  See tri_test_pre.
+			const float4 Q0 = th[r * 4 + 0], Q1 = th[r * 4 + 1], Q2 = th[r * 4 + 2];
+			const float v0[3] = {Q0.w, Q1.x, Q1.y}, v1[3] = {Q1.z, Q1.w, Q2.x}, v2[3] = {Q2.y, Q2.z, Q2.w};
+			float c0[3], c1[3];
+			for (int c = 0; c < 3; ++c) {
+				c0[c] = v0[c] - v2[c];
+				c1[c] = v1[c] - v2[c];
+			}
+			const bool s1 = std::fabs(c0[1]) > std::fabs(c0[0]);
+			const float mx = s1 ? std::fabs(c0[1]) : std::fabs(c0[0]);
+			const bool s2 = std::fabs(c0[2]) > mx;
+			const int rowP = s2 ? 2 : (s1 ? 1 : 0);
+			const int rowA = (s1 && !s2) ? 0 : 1, rowC = s2 ? 0 : 2;
+			const float p1q = c1[rowP] / c0[rowP];
+			const float a1 = std::fmaf(-p1q, c0[rowA], c1[rowA]);
+			const float d1 = std::fmaf(-p1q, c0[rowC], c1[rowC]);
+			const bool s3 = std::fabs(d1) > std::fabs(a1);
+			const float e1 = s3 ? d1 : a1;
+			const int rowE = s3 ? rowC : rowA;
 			float rankf;
-			const int32_t ri = (int32_t)r;
+			const int32_t ri = (int32_t)(((uint32_t)r << 4) | (uint32_t)(rowP | (rowE << 2)));
 			std::memcpy(&rankf, &ri, 4);
-			tw[rec * 4 + 3] = make_float4(th[r * 4 + 3].x, rankf, 0.0f, 0.0f);
+			tw[rec * 4 + 3] = make_float4(th[r * 4 + 3].x, rankf, p1q, e1);
 		}
 	}
 	lap("triangle records");
