@@ -445,17 +445,21 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 	// chunks of the full size a queue of a million rays would occupy two waves in three and the launch would
 	// last as long as one wave needs for its whole chunk.
 	chunk = min(chunk, max(64, (int)((unsigned)n / (gridDim.x * (TRACE_THREADS / 64) * 3u) + 63u) & ~63));
-	// The per-lane stack lives in LDS, one row of the array per entry; a lane's stack pointer is kept as the LDS address
-	// of its top entry (`top`), so that a push or a pop is one LDS instruction with a constant offset and no address
-	// arithmetic of its own.  Row 0 is never written: `top` points there while the stack is empty.
+	// The per-lane stack lives in LDS, one row of the array per entry, and grows downwards; a lane's stack pointer is
+	// kept as the LDS address of its top entry (`top`), so that a push or a pop is one LDS instruction with a constant
+	// offset and no address arithmetic of its own.  An empty stack points one row past the array.
+	// A node's four children are all written, sorted, to the four rows below `top` whether they are entered or not --
+	// the ones that are not sort to the far end, below what `top` then moves down to -- and the nearest is popped
+	// straight back: four stores and a load that cost no vector-ALU instruction, where choosing what to store did.
+	// The four rows of room that takes come out of the stack's depth: a ray whose stack reaches into the lowest four
+	// rows when it comes to a node does not fit.
 	__shared__ int stk[STACK + 1][TRACE_THREADS];
 	__shared__ unsigned char sPool[TRACE_THREADS / 64][128];  // leaf phase: lanes that want help | lanes that help, by rank
 	const int tid = threadIdx.x;
 	typedef __attribute__((address_space(3))) int lds_int;
 	constexpr int ROW = TRACE_THREADS;                          // ints from one stack entry of a lane to the next
-	lds_int* const stkEmpty = (lds_int*)&stk[0][tid];           // `top` of an empty stack
-	lds_int* const stkLast = (lds_int*)&stk[STACK][tid];        // the last entry there is room for
-	lds_int* const stkLimit = stkLast + ROW;                    // a node whose entered children would reach beyond this does not fit
+	lds_int* const stkEmpty = (lds_int*)&stk[0][tid] + (STACK + 1) * ROW;  // `top` of an empty stack (never dereferenced)
+	lds_int* const stkFloor = (lds_int*)&stk[4][tid];           // a node is visited only while `top` is at or above this row
 	lds_int* top = stkEmpty;
 	const unsigned lane = (unsigned)tid & 63u;
 	const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 			// tested on its own, exact box, exact slab predicate, exact triangle test; one leaf per lane and pass.
 #ifdef RTX_BOUNDS_CHECK
 			if (busy && pend0 >= 0 && (unsigned)((pend0 >> 1) + (pend0 & 1)) >= (unsigned)sc.nTris) {
-				printf("[rtx] k_trace_wide: leaf record %d (+%d) of %d (ray %d, sp %d, cur %d, pend1 %d)\n", pend0 >> 1, pend0 & 1, sc.nTris, j, (int)(top - stkEmpty) / ROW, cur, pend1);
+				printf("[rtx] k_trace_wide: leaf record %d (+%d) of %d (ray %d, sp %d, cur %d, pend1 %d)\n", pend0 >> 1, pend0 & 1, sc.nTris, j, (int)(stkEmpty - top) / ROW, cur, pend1);
 				atomicOr(sc.fault, FAULT_LEAF);
 				pend0 = pend1 = -1; cur = -1; top = stkEmpty;
 			}
@@ -704,12 +708,12 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 			int item = 0;  // what this lane looks at next: > 0 node, < 0 ~rank of a leaf, 0 nothing yet
 #ifdef RTX_BOUNDS_CHECK
 			if (cur >= sc.nWide) {
-				printf("[rtx] k_trace_wide: node %d of %d (ray %d, sp %d, pend %d %d)\n", cur, sc.nWide, j, (int)(top - stkEmpty) / ROW, pend0, pend1);
+				printf("[rtx] k_trace_wide: node %d of %d (ray %d, sp %d, pend %d %d)\n", cur, sc.nWide, j, (int)(stkEmpty - top) / ROW, pend0, pend1);
 				atomicOr(sc.fault, FAULT_NODE);
 				cur = -1; top = stkEmpty;
 			}
-			if (top < stkEmpty || top > stkLast || (int)(top - stkEmpty) % ROW != 0) {
-				printf("[rtx] k_trace_wide: stack pointer %d (ray %d)\n", (int)(top - stkEmpty), j);
+			if (top > stkEmpty || top < (lds_int*)&stk[0][tid] || (int)(stkEmpty - top) % ROW != 0) {
+				printf("[rtx] k_trace_wide: stack pointer %d (ray %d)\n", (int)(stkEmpty - top), j);
 				atomicOr(sc.fault, FAULT_STACK);
 				top = stkEmpty;
 			}
@@ -742,7 +746,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 				const unsigned nyd = r.ny ? hiy : loy, fyd = r.ny ? loy : hiy;
 				const unsigned nzd = r.nz ? hiz : loz, fzd = r.nz ? loz : hiz;
 				int cd[4] = {__float_as_int(w2.z), __float_as_int(w2.w), __float_as_int(w3.x), __float_as_int(w3.y)};
-				// key: ordered bits of what the children are sorted by, all ones for a child that is not entered
+				// key: ordered bits of what the children are sorted by (never zero), zero for a child that is not entered
 				unsigned key[4];
 				int nh = 0;
 #pragma unroll
@@ -758,11 +762,11 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 					// closest hit: nearest child first.  Any hit: the child the ray stays in longest first, where an
 					// occluder is likeliest (any order gives the same answer; the key stays below the "not
 					// entered" marker because the length is clamped to >= +0).
-					key[c] = !h ? 0xFFFFFFFFu : ANYHIT ? 0x7FFFFFFFu - __float_as_uint(fmaxf(x - e, 0.0f)) : __float_as_uint(e);
+					key[c] = !h ? 0u : ANYHIT ? 0x7FFFFFFFu - __float_as_uint(fmaxf(x - e, 0.0f)) : __float_as_uint(e);
 					nh += h ? 1 : 0;
 					if (STATS) boxTests += cd[c] != 0;
 				}
-				// sorting network on (key, code), nearest first
+				// sorting network on (key, code): the children that are not entered first, then the entered ones, nearest first
 #define RTX_CSWAP(i, j)                                     \
 	{                                                       \
 		const bool sw = key[i] > key[j];                    \
@@ -778,33 +782,30 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 				RTX_CSWAP(1, 3)
 				RTX_CSWAP(1, 2)
 #undef RTX_CSWAP
-				// the nearest is looked at next, the others wait with the farthest at the bottom: entry k of the sorted four
-				// (k = 1, 2, 3) goes nh - k rows above the present top
-				lds_int* above = top + nh * ROW;
-				if (__builtin_amdgcn_ballot_w64(above > stkLimit) != 0ull) {
-					if (above > stkLimit) {
+				if (__builtin_amdgcn_ballot_w64(top < stkFloor) != 0ull) {
+					if (top < stkFloor) {
 						// no room: the ray starts over in the binary-tree kernel, whose stack covers its whole tree
 						unsafeList[atomicAdd(unsafeCount, 1u)] = j;
 						if (STATS) overflows++;
 						busy = false;
 						top = stkEmpty;
-						above = stkEmpty;
 						nh = 0;
 						pend0 = -1;
 					}
 				}
-				if (nh > 3) top[ROW] = cd[3];
-				if (nh > 2) above[-2 * ROW] = cd[2];
-				if (nh > 1) above[-ROW] = cd[1];
-				if (nh > 0) {
-					top = above - ROW;
-					item = cd[0];
-				}
+				// all four go below the top, the farthest next to it; the top then moves down over the nh entered ones
+				lds_int* low = top - 4 * ROW;
+				asm("" : "+v"(low));  // (one subtraction and four constant offsets; seen through, it becomes four additions)
+				low[0] = cd[0];
+				low[ROW] = cd[1];
+				low[2 * ROW] = cd[2];
+				low[3 * ROW] = cd[3];
+				top -= nh * ROW;
 				cur = -1;
 			}
-			if (item == 0 && top != stkEmpty) {
+			if (top != stkEmpty) {
 				item = *top;
-				top -= ROW;
+				top += ROW;
 			}
 			if (item < 0) {
 				// a leaf: keep it and look at what comes after it
@@ -813,7 +814,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 				item = 0;
 				if (pend1 < 0 && top != stkEmpty) {
 					item = *top;
-					top -= ROW;
+					top += ROW;
 					if (item < 0) {
 						pend1 = ~item;
 						item = 0;

@@ -544,9 +544,10 @@ int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float
 				  int* unsafeList, unsigned* unsafeCount, const unsigned* nDev, int* longList, unsigned* longCount) {
 	const int wanted = nDev ? s->numCUs * s->traceBlocksPerCU : (n + TRACE_THREADS - 1) / TRACE_THREADS;
 	dim3 grid(std::min(wanted, s->numCUs * s->traceBlocksPerCU)), block(TRACE_THREADS);
-	// The stack is no deeper than wideStackCap entries however deep the tree: a ray that would need more
-	// moves to the binary-tree kernel.  Fewer entries, more resident waves.
-	const int need = std::min(s->wideStackNeed, s->wideStackCap);
+	// The stack has wideStackCap + 1 rows however deep the tree, and a node's children take the four rows below the top
+	// before the top moves: a ray that comes to a node with more than wideStackCap - 3 entries waiting moves to the
+	// binary-tree kernel.  The small stack serves the trees that can never get there (and RTX_WIDE_STACK=16).
+	const bool smallStack = s->wideStackCap <= 16 || s->wideStackNeed <= 13;
 	const bool st = s->instrumented;
 	unsigned long long* stats = s->dStats.p;
 #define RTX_LAUNCH(STK, ST)                                                                                              \
@@ -554,7 +555,7 @@ int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float
 					   unsafeList, unsafeCount, s->traceRefill, s->traceChunk, s->traceTriBatch, nDev, longList, longCount, \
 					   s->longVisits, s->longVisits == INT_MAX ? -1 : s->numCUs * s->longBlocksPerCU * (TRACE_THREADS / 64) * s->smallQueueFactor, \
 					   s->longVisits == INT_MAX ? INT_MAX : s->tailVisits, s->longVisits == INT_MAX ? 0 : s->tailLanes)
-	if (need <= 16) {
+	if (smallStack) {
 		if (st) RTX_LAUNCH(16, true); else RTX_LAUNCH(16, false);
 	}
 	else {
