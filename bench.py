@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: a step is N frames on N GPUs (fixed work per GPU); strong: a step is one frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-frame-calls", action="store_true",
+                    help="leave out the loop of single-frame calls (profiling runs: every launch of the run then is a launch of the timed workload)")
     ap.add_argument("--no-instrument", action="store_true")
     args = ap.parse_args()
     args.size_given = args.width is not None or args.height is not None
@@ -258,7 +260,7 @@ def main():
     # share of it (what the per-frame out_NNN.png contract of the reference costs).
     other_run = None
     single_calls = None
-    if world == 1 and frames_per_step > 1:
+    if world == 1 and frames_per_step > 1 and not args.no_single_frame_calls:
         # one frame per call, as a caller that needs the accumulator between frames would render
         single_calls = timed_loop(1, 2, max(4, min(args.steps, 8)))
     if world > 1 and args.balance == "static":
@@ -346,7 +348,7 @@ def main():
             rays_per_launch = rays_total / launches
             traffic = None
             # the per-launch figures of the profile belong to the launches of the default single-GPU workload
-            same_launches = world == 1 and (sc.width, sc.height, sc.max_depth) == (1920, 1080, 4)
+            same_launches = world == 1 and (sc.width, sc.height, sc.max_depth) == (1920, 1080, 4) and frames_per_step == prof.get("frames_per_step", 1)
             if not same_launches:
                 pk = {k: v for k, v in pk.items() if k in ("lane_util", "issue_model_frac", "valu_class_share")}
             if "fetch_size_bytes_per_launch" in pk:

@@ -71,6 +71,13 @@ def main(src, dst):
     out = []
     measured = {"source": "profiles/" + os.path.basename(dst), "commit": git_state()}
     kt_ms = {}
+    # the workload of the profiled command: the JSON line bench.py printed in the kernel-trace pass
+    try:
+        for line in open(src + "/kt.log"):
+            if line.startswith("{") and '"frames_per_step"' in line:
+                measured["frames_per_step"] = json.loads(line)["config"]["frames_per_step"]
+    except (OSError, ValueError, KeyError):
+        pass
     for f in glob.glob(src + "/kt/*/*kernel_stats.csv"):
         out.append("== rocprofv3 --kernel-trace --stats  (per kernel: calls, total ms, average us, share)")
         for r in csv.DictReader(open(f)):

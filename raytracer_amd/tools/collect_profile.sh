@@ -8,7 +8,7 @@ set -u
 D=${1:-gpurun_out/prof}
 export TMPDIR=/tmp
 mkdir -p "$D"
-B="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline"
+B="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-single-frame-calls"
 pass() {  # name, then the rocprofv3 options
 	local name=$1; shift
 	timeout -s KILL 200 rocprofv3 "$@" --output-format csv -d "$D/$name" -- $B > "$D/$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$D/$name.log"; exit 1; }
