@@ -1,4 +1,4 @@
-"""Static instruction budget of k_trace_wide<24, false, false> (the closest-hit traversal kernel of the benchmark): compiles
+"""Static instruction budget of k_trace_wide<16, false, false> (the closest-hit traversal kernel of the benchmark): compiles
 raytracer_amd/csrc/rtx_hip.hip to gfx950 assembly with the product's flags, cuts the kernel into its phases at anchors
 in the instruction stream, and tabulates every phase by instruction class and -- for the walk step -- by purpose.
 
@@ -21,7 +21,7 @@ import tempfile
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "--cuda-device-only", "-S"]
-KERNEL = "k_trace_wideILi24ELb0ELb0E"
+KERNEL = "k_trace_wideILi16ELb0ELb0E"
 
 FAST = re.compile(r"^v_(fma_f32|fmac_f32|mul_f32|add_f32|sub_f32|subrev_f32|and_b32|or_b32|xor_b32|not_b32|add_u32|sub_u32|subrev_u32|lshrrev_b32|ashrrev_i32|mov_b32|mov_b64|cndmask_b32_e32)")
 
@@ -137,7 +137,7 @@ def analyze():
                 purp[p] += 1
                 purp_class[p][klass(op)] += 1
     out = []
-    out.append("Static instruction budget of k_trace_wide<24, false, false> (closest hit, 24-entry stack), hipcc " + " ".join(FLAGS[:5]))
+    out.append("Static instruction budget of k_trace_wide<16, false, false> (closest hit, 16-entry stack), hipcc " + " ".join(FLAGS[:5]))
     out.extend("  " + m.strip() for m in dict.fromkeys(meta))
     out.append("")
     cols = ["valu fast", "valu slow", "salu", "branch", "wait/nop", "lds", "vmem", "smem", "other"]

@@ -429,7 +429,7 @@ __device__ __forceinline__ int wide_leaf_test(const float4* __restrict__ T, cons
 }
 
 template <int STACK, bool ANYHIT, bool STATS>
-__global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_trace_wide(DevScene sc, const float4* __restrict__ rayO,
+__global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(STACK <= 16 ? 7 : 6, STACK <= 16 ? 7 : 6))) void k_trace_wide(DevScene sc, const float4* __restrict__ rayO,
 															   const float4* __restrict__ rayD, float4* __restrict__ hits,
 															   int n, unsigned long long* __restrict__ stats,
 															   unsigned* __restrict__ work, int* __restrict__ unsafeList,
@@ -784,8 +784,10 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 #undef RTX_CSWAP
 				if (__builtin_amdgcn_ballot_w64(top < stkFloor) != 0ull) {
 					if (top < stkFloor) {
-						// no room: the ray starts over in the binary-tree kernel, whose stack covers its whole tree
-						unsafeList[atomicAdd(unsafeCount, 1u)] = j;
+						// no room: the ray starts over in the wave-per-ray kernel, whose stack is a thousand entries deep (in
+						// the binary-tree kernel, whose stack covers its whole tree, where that kernel is not run)
+						if (smallQueue >= 0) longList[atomicAdd(longCount, 1u)] = j;
+						else unsafeList[atomicAdd(unsafeCount, 1u)] = j;
 						if (STATS) overflows++;
 						busy = false;
 						top = stkEmpty;

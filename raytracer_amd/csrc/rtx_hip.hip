@@ -212,7 +212,8 @@ struct rtx_scene {
 	int treeDepth = 0;
 	int stackNeed = 32;  // deepest interior node: the traversal pushes at most once per interior level
 	int wideStackNeed = 52;  // wide traversal: entries waiting when every child of every node on a path is hit
-	int wideStackCap = 24;   // RTX_WIDE_STACK: 16 or 24
+	int wideStackCap = 16;   // RTX_WIDE_STACK: 16 or 24 entries (+ 1 row) of the wide traversal's stack
+	int wideBlocksPerCU = 7; // grid of k_trace_wide in blocks per CU (RTX_TRACE_BLOCKS_PER_CU; six at most with the 24-entry stack)
 	// Rays per primary sample at each level: popRatio the largest seen so far (0: nothing seen yet), capRatio what
 	// the queues of the next batch are sized for.  Levels up to capKnown rest on counts a batch has reported, the
 	// deeper ones on a guess.
@@ -542,12 +543,14 @@ int launch_exact_t(rtx_scene* s, const DevScene& d, const float4* ro, const floa
 template <bool ANYHIT>
 int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float4* rd, float4* hits, int n, unsigned* work,
 				  int* unsafeList, unsigned* unsafeCount, const unsigned* nDev, int* longList, unsigned* longCount) {
-	const int wanted = nDev ? s->numCUs * s->traceBlocksPerCU : (n + TRACE_THREADS - 1) / TRACE_THREADS;
-	dim3 grid(std::min(wanted, s->numCUs * s->traceBlocksPerCU)), block(TRACE_THREADS);
-	// The stack has wideStackCap + 1 rows however deep the tree, and a node's children take the four rows below the top
-	// before the top moves: a ray that comes to a node with more than wideStackCap - 3 entries waiting moves to the
-	// binary-tree kernel.  The small stack serves the trees that can never get there (and RTX_WIDE_STACK=16).
-	const bool smallStack = s->wideStackCap <= 16 || s->wideStackNeed <= 13;
+	// The stack has 17 rows however deep the tree, and a node's children take the four rows below the top before the
+	// top moves: a ray that comes to a node with more than thirteen entries waiting moves to the wave-per-ray kernel
+	// (the atrium: 1 ray in 12,000).  With 18 KB of LDS and 72 registers seven blocks are resident per CU, which is
+	// worth 2.7 % over the six that 25 rows allow (RTX_WIDE_STACK=24).
+	const bool smallStack = s->wideStackCap <= 16;
+	const int perCU = smallStack ? s->wideBlocksPerCU : std::min(s->wideBlocksPerCU, 6);
+	const int wanted = nDev ? s->numCUs * perCU : (n + TRACE_THREADS - 1) / TRACE_THREADS;
+	dim3 grid(std::min(wanted, s->numCUs * perCU)), block(TRACE_THREADS);
 	const bool st = s->instrumented;
 	unsigned long long* stats = s->dStats.p;
 #define RTX_LAUNCH(STK, ST)                                                                                              \
@@ -1082,7 +1085,7 @@ RTX_API int rtx_scene_create(rtx_scene** out, int device) {
 	if (const char* e = std::getenv("RTX_TAIL_LANES")) s->tailLanes = std::max(0, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_MERGE_BLOCKS")) s->mergeBlocks = std::max(1ll, std::atoll(e));
 	if (const char* e = std::getenv("RTX_TRACE_TRI_BATCH")) s->traceTriBatch = std::max(1, std::min(64, std::atoi(e)));
-	if (const char* e = std::getenv("RTX_TRACE_BLOCKS_PER_CU")) s->traceBlocksPerCU = std::max(1, std::atoi(e));
+	if (const char* e = std::getenv("RTX_TRACE_BLOCKS_PER_CU")) s->wideBlocksPerCU = s->traceBlocksPerCU = std::max(1, std::atoi(e));
 	if (const char* e = std::getenv("RTX_TRACE_BINARY")) s->forceBinary = std::atoi(e) != 0;
 	if (const char* e = std::getenv("RTX_SYNC_LAUNCHES")) s->syncLaunches = std::atoi(e) != 0;
 	if (const char* e = std::getenv("RTX_WORST_CASE_QUEUES")) s->worstCaseQueues = std::atoi(e) != 0;
