@@ -7,7 +7,7 @@ What is derived for the traversal kernel k_trace_wide (all template variants tog
   lane_util   = SQ_THREAD_CYCLES_VALU / (64 * SQ_INSTS_VALU): active lanes per vector-ALU instruction / 64
   issue model = sum over instruction classes (sq3 pass: FP32 add / mul / fma, conversions, transcendentals counted by
                 the hardware, the rest split into fast and slow opcodes by the static mix of the walk step's code)
-                of instructions / issue rate of the class (tools/valu_rate at six waves per SIMD), over 1,024 SIMDs,
+                of instructions / issue rate of the class (tools/valu_rate at the kernel's seven waves per SIMD), over 1,024 SIMDs,
                 against the launch time of the kernel trace: 1.0 = the launch lasts as long as issuing takes
   valu_busy_uncalibrated = 4 * SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 * SIMDs): kept for comparison with earlier
                 summaries; it is 4 x instructions / SIMD-cycles from two different runs, not a busy share
@@ -170,7 +170,7 @@ def main(src, dst):
         if salu:
             out.append("   per vector instruction: %.3f scalar, %.4f vector-memory reads, %.4f LDS" % (salu / insts, vmem / insts, lds / insts))
         # ---- issue-time model: the kernel's vector instructions by class (sq3 pass) over the issue rates measured by
-        # tools/valu_rate at six waves per SIMD (rates.log).  FP32 add / mul / fma and conversions are counted by the
+        # tools/valu_rate at the kernel's occupancy (rates.log).  FP32 add / mul / fma and conversions are counted by the
         # hardware; the rest (integer, compares, min/max, selects, moves) issues at the fast or the slow rate depending
         # on the opcode, and is split by the share the walk step's code has of each (profiles/isa_table.py).
         sq3, sq3c = passes.get("sq3", ({}, {}))
@@ -178,7 +178,8 @@ def main(src, dst):
         rp = os.path.join(src, "rates.log")
         if os.path.exists(rp):
             for line in open(rp):
-                if line.startswith("rate ") and "waves_per_simd 6" in line:
+                # the traversal kernel's own occupancy: seven waves per SIMD (six in logs taken before it had seven)
+                if line.startswith("rate ") and ("waves_per_simd 7" in line or ("waves_per_simd 6" in line and line[5:26].strip() not in rates)):
                     name = line[5:26].strip()
                     rates[name] = float(line.split("per_simd_instr_per_ns")[1])
         tot3, n3 = family(sq3, sq3c, K, "SQ_INSTS_VALU")
@@ -208,7 +209,7 @@ def main(src, dst):
             rec["issue_model_other_fast_share"] = fast_share
             out.append("   vector instructions by class (sq3 pass, %d dispatches): " % n3 + ", ".join("%s %.1f %%" % (c, 100.0 * v / tot3) for c, v in cls.items() if c != "FLOPS_FP32") +
                        ", other %.1f %%" % (100.0 * (rest - cls["INT32"]) / tot3))
-            out.append("   rates at six waves per SIMD (tools/valu_rate, wave-instructions per ns per SIMD): fma %.3f mul %.3f add %.3f cvt %.3f, fast integer/move %.3f, slow (min/max, compare, select, 3-operand) %.3f" % (
+            out.append("   rates at the kernel's occupancy (tools/valu_rate, wave-instructions per ns per SIMD): fma %.3f mul %.3f add %.3f cvt %.3f, fast integer/move %.3f, slow (min/max, compare, select, 3-operand) %.3f" % (
                 rates.get("v_fma_f32", 0), rates.get("v_mul_f32", 0), rates.get("v_add_f32", 0), rates.get("v_cvt_f32_ubyte1", 0), r_fast, r_slow))
             out.append("   issue-time model: sum over classes of instructions / rate, over %d SIMDs = %.3f ms per launch (%.0f %% of the rest at the fast rate, as in the walk step's code;" % (SIMDS, model_ms, 100 * fast_share))
             out.append("      all of it fast: %.3f ms, all of it slow: %.3f ms)" % (lo_ms, hi_ms))

@@ -90,7 +90,7 @@ void run(int blocksPerCU, int numCUs) {
 
 template <int KIND>
 void run_all(int numCUs) {
-	for (int b : {2, 6}) run<KIND>(b, numCUs);
+	for (int b : {2, 6, 7}) run<KIND>(b, numCUs);
 	if constexpr (KIND + 1 < NKINDS) run_all<KIND + 1>(numCUs);
 }
 
