@@ -935,6 +935,40 @@ def test_frames_of_a_merged_batch_each_give_their_image(libs):
     assert lib.rtx_render_frames_tonemapped(rt.h, 1, 2, C.cast(ptrs, C.c_void_p)) == -1 and b"null image" in lib.rtx_last_error()
 
 
+def test_rays_outside_the_wide_traversal_go_where_they_belong(libs):
+    """Directions with a component that is tiny (below 2^-99, denormal), huge (above 2^126), zero, all zero, infinite or
+    NaN, and NaN origins, through rtx_trace_rays in both modes: the production path (the wide traversal, the rays it
+    leaves to the binary-tree kernel, the rays it answers itself) gives what the exhaustive traversal of the reference's
+    tree gives."""
+    sc = scenes.mixed_scene(seed=4, width=32, height=32)
+    rt = gpu_scene(sc)
+    rng = np.random.default_rng(12)
+    n = 4096
+    o = rng.uniform(-30, 30, (n, 3)).astype(np.float32)
+    o[:, 1] = np.abs(o[:, 1]) + 1.0
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    special = np.array([0.0, -0.0, 1e-30, -1e-31, 1e-38, 1e-45, 2.0 ** -99, np.nextafter(np.float32(2.0 ** -99), np.float32(0)), 2.0 ** 126,
+                        np.nextafter(np.float32(2.0 ** 126), np.float32(np.inf)), 3e38, -3.4e38, np.inf, -np.inf, np.nan], np.float32)
+    for k in range(n):
+        m = k % 7
+        if m < 3:
+            d[k, m] = special[(k // 7) % len(special)]
+        elif m == 3:
+            d[k, 0] = special[(k // 7) % len(special)]
+            d[k, 2] = special[(k // 11) % len(special)]
+        elif m == 4:
+            d[k] = special[(k // 7) % 6]
+        elif m == 5:
+            o[k, k % 3] = np.nan
+    with np.errstate(all="ignore"):
+        ids0, tab0 = rt.trace_rays(o, d, mode=0)
+        ids1, tab1 = rt.trace_rays(o, d, mode=1)
+    assert (ids0 >= 0).sum() > n // 8
+    assert np.array_equal(ids0, ids1)
+    hit = ids0 >= 0
+    assert_bits_equal(tab0[hit], tab1[hit], "t/alpha/beta of the special rays")
+
+
 def test_error_paths(libs):
     lib = api.hip_lib()
     h = C.c_void_p()
