@@ -436,7 +436,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(S
 															   unsigned* __restrict__ unsafeCount, int refill, int chunk,
 															   int triBatch, const unsigned* __restrict__ nDev,
 															   int* __restrict__ longList, unsigned* __restrict__ longCount, int longVisits,
-															   int smallQueue, int tailVisits, int tailLanes) {
+															   int smallQueue, int tailVisits, int tailLanes, int retire) {
 	if (nDev) n = (int)min(*nDev, (unsigned)n);  // n: capacity of the arrays
 	// A queue of a few thousand rays cannot fill the chip with one ray per lane; its launch would last as long as
 	// its longest ray walked by a single lane.  All its rays go to k_trace_long, a wave each, at once.
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(S
 	unsigned alonePasses = 0, aloneLanes = 0, helpedLanes = 0;  // likewise
 	unsigned myVisits = 0, maxVisits = 0, over100 = 0, over300 = 0;
 	int cnext = 0, cend = 0;
-	bool more = true, firstChunk = true;
+	bool more = true, firstChunk = true, lastChunk = false;
 	int j = -1, cur = -1;
 	RaySlab r;
 	r.ox = r.oy = r.oz = r.ix = r.iy = r.iz = r.mx = r.my = r.mz = 0.0f;
@@ -496,11 +496,11 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(S
 					base = (blockIdx.x * (TRACE_THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6)) * (unsigned)chunk;
 					firstChunk = false;
 				}
-				else {
+				else if (!lastChunk) {
 					if (lane == 0) base = atomicAdd(work, (unsigned)chunk);
 					base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + gridDim.x * (TRACE_THREADS / 64) * (unsigned)chunk;
 				}
-				if (base >= (unsigned)n) {
+				if (lastChunk || base >= (unsigned)n) {
 					more = false;
 					cnext = cend = 0;
 					// The queue is exhausted: from here on the launch lasts as long as this wave's slowest ray.  Rays
@@ -510,6 +510,17 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(S
 				else {
 					cnext = (int)base;
 					cend = min((int)base + chunk, n);
+					// Left to themselves all waves of the grid find the queue exhausted at about the same time, and the launch
+					// ends with every one of them running its last rays out on ever fewer lanes, side by side.  Instead the
+					// waves leave one after the other as the queue runs low: this chunk is a wave's last one when what remains
+					// behind it is less than `retire` rays for each wave that ranks below it (the rank is a hash of the wave's
+					// number, which spreads the leavers over the SIMDs).  Those that stay find the vector ALUs less contended.
+					if (retire > 0) {
+						const unsigned g = blockIdx.x * (TRACE_THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
+						const unsigned long long rank = (g * 2654435761u) >> 16;  // 0 .. 65535
+						const unsigned long long room = (rank * gridDim.x * (TRACE_THREADS / 64) * (unsigned long long)retire) >> 16;
+						lastChunk = (unsigned long long)(n - cend) < room;
+					}
 				}
 			}
 			const int take = min(nidle, cend - cnext);

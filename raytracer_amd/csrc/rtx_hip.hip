@@ -180,6 +180,7 @@ struct rtx_scene {
 	bool lastEndFresh = false;
 	int shadeBlocksPerCU = 6;        // grid of k_shade (RTX_SHADE_BLOCKS_PER_CU): a multiple of the three blocks of 512 threads a CU holds at once, so that
 	                                 // the last set of blocks is a full one (four per CU: a third of the chip works through the last quarter)
+	int retireBacklog = 128;         // rays left per remaining wave below which a wave of k_trace_wide takes its last chunk (RTX_RETIRE_BACKLOG; 0: never)
 	int tailLanes = 2;               // a wave down to this many rays after the queue's end hands them over at once (RTX_TAIL_LANES)
 	int tailVisits = 32;             // the same allowance for rays still in flight once a wave finds the queue exhausted (RTX_TAIL_VISITS)
 	long long mergeBlocks = 524288;  // frames of a multi-frame call share a batch up to this many 4x4-pixel blocks (RTX_MERGE_BLOCKS): four 1080p frames or one
@@ -557,7 +558,7 @@ int launch_wide_t(rtx_scene* s, const DevScene& d, const float4* ro, const float
 	hipLaunchKernelGGL((k_trace_wide<STK, ANYHIT, ST>), grid, block, 0, s->stream, d, ro, rd, hits, n, stats, work,      \
 					   unsafeList, unsafeCount, s->traceRefill, s->traceChunk, s->traceTriBatch, nDev, longList, longCount, \
 					   s->longVisits, s->longVisits == INT_MAX ? -1 : s->numCUs * s->longBlocksPerCU * (TRACE_THREADS / 64) * s->smallQueueFactor, \
-					   s->longVisits == INT_MAX ? INT_MAX : s->tailVisits, s->longVisits == INT_MAX ? 0 : s->tailLanes)
+					   s->longVisits == INT_MAX ? INT_MAX : s->tailVisits, s->longVisits == INT_MAX ? 0 : s->tailLanes, s->retireBacklog)
 	if (smallStack) {
 		if (st) RTX_LAUNCH(16, true); else RTX_LAUNCH(16, false);
 	}
@@ -1082,6 +1083,7 @@ RTX_API int rtx_scene_create(rtx_scene** out, int device) {
 	if (const char* e = std::getenv("RTX_LONG_VISITS")) s->longVisits = std::atoi(e) > 0 ? std::atoi(e) : INT_MAX;
 	if (const char* e = std::getenv("RTX_TAIL_VISITS")) s->tailVisits = std::max(0, std::atoi(e));
 	if (const char* e = std::getenv("RTX_SHADE_BLOCKS_PER_CU")) s->shadeBlocksPerCU = std::max(1, std::min(64, std::atoi(e)));
+	if (const char* e = std::getenv("RTX_RETIRE_BACKLOG")) s->retireBacklog = std::max(0, std::atoi(e));
 	if (const char* e = std::getenv("RTX_TAIL_LANES")) s->tailLanes = std::max(0, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("RTX_MERGE_BLOCKS")) s->mergeBlocks = std::max(1ll, std::atoll(e));
 	if (const char* e = std::getenv("RTX_TRACE_TRI_BATCH")) s->traceTriBatch = std::max(1, std::min(64, std::atoi(e)));

@@ -619,6 +619,39 @@ def test_long_rays_taken_over_by_a_whole_wave(libs, monkeypatch, visits):
     assert_bits_equal(t0[i0 >= 0], t1[i0 >= 0], "arbitrary rays")
 
 
+def test_waves_that_leave_the_queue_early_lose_no_ray(libs, monkeypatch):
+    """The waves of the one-ray-per-lane kernel leave one after the other as a level's queue runs low (a wave's chunk is
+    its last one when few rays per remaining wave are left behind it).  Whatever the threshold -- never, the default, or
+    so high that most waves leave after their first chunk and a few work through the rest -- every ray of the queue is
+    traced once: same ray counts per level, same accumulator bit for bit, and that accumulator is the restatement's on
+    blocks scattered over the frame.  960x540 gives every level but the first more rays than the grid's first chunks
+    hold, so chunks are claimed from the shared cursor."""
+    sc = scenes.atrium_scene(width=960, height=540, max_depth=4)
+    nodes = api.build_bvh(sc.tris)
+    got = {}
+    for backlog in ("0", None, "1024"):
+        if backlog is None:
+            monkeypatch.delenv("RTX_RETIRE_BACKLOG", raising=False)
+        else:
+            monkeypatch.setenv("RTX_RETIRE_BACKLOG", backlog)
+        rt = api.RayTracer(0)
+        rt.load_scene(sc, nodes)
+        rt.reset()
+        rt.render(1, 2)
+        st = rt.stats()
+        got[backlog] = (rt.accum(), st["rays_per_level"], st["rays"])
+        del rt
+    monkeypatch.delenv("RTX_RETIRE_BACKLOG", raising=False)
+    for backlog in ("0", "1024"):
+        assert got[backlog][1] == got[None][1] and got[backlog][2] == got[None][2]
+        assert_bits_equal(got[None][0], got[backlog][0], "accumulator, RTX_RETIRE_BACKLOG=%s against the default" % backlog)
+    O = binding.Oracle()
+    load_into(O, sc, build=False)
+    O.set_nodes(nodes)
+    xy = scattered_blocks(sc.width, sc.height, 60, seed=540)
+    assert_pixels_equal(O, (1, 2), xy, got["1024"][0], "60 scattered 4x4 blocks vs CPU")
+
+
 def test_multi_million_triangle_mesh_depth_8(libs):
     """The stress configuration in small: a 2-million-triangle displaced mesh at depth 8 (finely tessellated, so
     grazing rays visit hundreds of nodes and the wave-per-ray kernel gets real work).  Culled traversal ==
