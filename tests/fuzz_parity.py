@@ -1,0 +1,177 @@
+"""Differential fuzzing of the HIP path (through the C ABI) against the CPU restatement: random small scenes of four
+kinds, cameras (jittered, on round coordinates, looking along an axis, rolled), render parameters, frame counts and batches
+of awkward rays (axis-parallel, from round coordinates, from vertices towards vertices, along box planes, tiny and huge
+directions), under random settings of the traversal's scheduling knobs (which kernel takes small queues, stack depth, the
+allowance before a whole wave takes a ray over, when waves leave the queue, refill and leaf-phase thresholds, chunk size),
+none of which may change a result.  Primary-hit ids and t/alpha/beta in the culled and the exhaustive mode, accumulators
+over one to three frames and the hits of the ray batches are compared bit for bit.
+
+    python tests/fuzz_parity.py <first seed> <count> [seconds]      # needs an MI355X
+
+tests/test_gpu_fuzz.py runs a fixed range of seeds with the GPU suite; campaigns over seeds 100..4099 and 5000..10999 (fifteen
+minutes on one MI355X) found no difference."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+from oracle import binding  # noqa: E402
+from raytracer_amd import api, scenes  # noqa: E402
+from util import bits, load_into  # noqa: E402
+
+KNOBS = ("RTX_SMALL_QUEUE", "RTX_WIDE_STACK", "RTX_LONG_VISITS", "RTX_RETIRE_BACKLOG", "RTX_TRACE_REFILL", "RTX_TRACE_TRI_BATCH",
+         "RTX_TRACE_CHUNK")
+
+
+def differ(a, b):
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    neq = bits(a) != bits(b)
+    neq &= ~(np.isnan(a) & np.isnan(b))
+    return int(neq.sum())
+
+
+def one_scene(seed):
+    """Builds the scene of `seed`, renders and traces it on both sides; returns (description, list of differences)."""
+    rng = np.random.default_rng(1000 + seed)
+    kind = int(rng.integers(0, 4))
+    w, h = int(rng.integers(3, 90)), int(rng.integers(3, 70))
+    depth = int(rng.integers(1, 6))
+    nd, ns = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    if kind <= 1:
+        sc = scenes.mixed_scene(seed=seed, width=w, height=h, max_depth=depth, n_diff=nd, n_spec=ns, with_sky=bool(rng.integers(0, 2)),
+                                ior=float(rng.uniform(1.05, 2.2)), with_tex=bool(rng.integers(0, 2)), detail=float(rng.uniform(0.3, 1.6)))
+    elif kind == 2:
+        sc = scenes.atrium_scene(width=w, height=h, max_depth=min(depth, 4), n_diff=min(nd, 2), n_spec=min(ns, 2),
+                                 detail=float(rng.uniform(0.08, 0.3)), tex_size=32, seed=seed)
+    else:
+        sc = scenes.heightfield_scene(n_tris=int(rng.integers(200, 6000)), width=w, height=h, seed=seed)
+        sc.max_depth, sc.n_diff, sc.n_spec = depth, min(nd, 2), min(ns, 2)
+    # camera: eye and target jittered, sometimes on round coordinates, sometimes looking along an axis, sometimes rolled
+    eye = np.array(sc.eye, np.float32) + rng.normal(0, 3, 3).astype(np.float32)
+    at = np.array(sc.at, np.float32) + rng.normal(0, 3, 3).astype(np.float32)
+    view = int(rng.integers(0, 5))
+    if view == 0:
+        eye, at = np.round(eye), np.round(at)
+    elif view == 1:
+        at = eye.copy()
+        at[int(rng.integers(0, 3))] += np.float32(rng.choice([-20, 20]))
+    sc.eye, sc.at = tuple(float(x) for x in eye), tuple(float(x) for x in at)
+    sc.focal = float(rng.uniform(15, 120))
+    sc.rotate = float(rng.choice([0.0, 0.0, rng.uniform(-180, 180)]))
+    sc.seed = int(rng.integers(0, 2**31))
+    if rng.integers(0, 3) == 0:
+        sc.bg = tuple(float(x) for x in rng.uniform(0, 1, 3))
+    # scheduling knobs of the traversal, read when the scene object is created
+    env = {}
+    if rng.integers(0, 4) != 0:
+        env["RTX_SMALL_QUEUE"] = "0"           # small queues through the one-ray-per-lane kernel, not the wave-per-ray one
+    env["RTX_WIDE_STACK"] = str(rng.choice([16, 24]))
+    allowance = int(rng.choice([-1, 0, 3, 12]))
+    if allowance >= 0:
+        env["RTX_LONG_VISITS"] = str(allowance)
+    env["RTX_RETIRE_BACKLOG"] = str(rng.choice([0, 128, 1000]))
+    env["RTX_TRACE_REFILL"] = str(rng.choice([1, 8, 16, 40, 64]))
+    env["RTX_TRACE_TRI_BATCH"] = str(rng.choice([1, 12, 28, 50, 64]))
+    env["RTX_TRACE_CHUNK"] = str(rng.choice([64, 256]))
+    saved = {k: os.environ.get(k) for k in KNOBS}
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    try:
+        rt = api.RayTracer(0)
+    finally:
+        for k in KNOBS:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+    O = load_into(binding.Oracle(), sc)
+    rt.load_scene(sc)
+    msg = []
+    ids_o, tab_o = O.primary_hits()
+    for m in (0, 1):
+        ids_g, tab_g = rt.primary_hits(m)
+        if not np.array_equal(ids_o, ids_g):
+            msg.append("primary ids, mode %d: %d differ" % (m, int((ids_o != ids_g).sum())))
+        else:
+            hit = ids_o >= 0
+            n = differ(tab_o[hit], tab_g[hit])
+            if n:
+                msg.append("primary t/alpha/beta, mode %d: %d values differ" % (m, n))
+    frames = int(rng.integers(1, 4))
+    want = np.zeros((sc.height, sc.width, 4), np.float32)
+    O.reset_counts()
+    for f in range(1, frames + 1):
+        O.render_rows(f, want, nthreads=16)
+    rt.reset()
+    rays = 0
+    if rng.integers(0, 2):
+        rt.render(1, frames)
+        rays = rt.stats()["rays"]
+    else:
+        for f in range(1, frames + 1):
+            rt.render(f, 1)
+            rays += rt.stats()["rays"]
+    n = differ(want[..., :3], rt.accum()[..., :3])
+    if n:
+        msg.append("accumulator: %d values differ" % n)
+    if rays != O.ray_count():
+        msg.append("rays: %d against %d" % (rays, O.ray_count()))
+    st = rt.stats()
+    # rays from inside the scene's bounds with the awkward ones mixed in
+    V = sc.tris["v"].reshape(-1, 4)[:, :3].astype(np.float32)
+    nr = 6000
+    o = rng.uniform(V.min(0) - 1, V.max(0) + 1, (nr, 3)).astype(np.float32)
+    d = rng.normal(0, 1, (nr, 3)).astype(np.float32)
+    d[:300, int(rng.integers(0, 3))] = 0
+    a, b = rng.choice(3, 2, replace=False)
+    d[300:500, a] = 0
+    d[300:500, b] = 0
+    o[500:1500] = np.round(o[500:1500])
+    d[1500:1600] *= np.float32(1e-6)
+    d[1600:1700] *= np.float32(1e6)
+    k = rng.integers(0, len(V), 600)
+    k2 = rng.integers(0, len(V), 600)
+    o[1700:2300] = V[k]                      # from vertices
+    d[1700:2300] = V[k2] - V[k]              # towards other vertices: edge and corner hits
+    o[2300:2600, 0] = V[rng.integers(0, len(V), 300), 0]   # on x planes of boxes, running along them
+    d[2300:2600, 0] = 0
+    ids_ro, tab_ro = O.closest_hits(o, d)
+    for m in (0, 1):
+        ids_rg, tab_rg = rt.trace_rays(o, d, m)
+        if not np.array_equal(ids_ro, ids_rg):
+            msg.append("ray batch, mode %d: %d ids differ" % (m, int((ids_ro != ids_rg).sum())))
+        else:
+            hit = ids_ro >= 0
+            n = differ(tab_ro[hit], tab_rg[hit])
+            if n:
+                msg.append("ray batch t/alpha/beta, mode %d: %d values differ" % (m, n))
+    what = "seed %d kind %d %dx%d depth %d diffuse %d specular %d, %d triangles, %d frame(s), %d rays by whole waves, %d set aside, %s" % (
+        seed, kind, w, h, depth, sc.n_diff, sc.n_spec, len(sc.tris), frames, st["rays_wave_traced"], st["rays_set_aside"],
+        " ".join("%s=%s" % (k[4:], v) for k, v in env.items()))
+    return what, msg
+
+
+def run(first, count, seconds=1e9, verbose=False):
+    """Scenes of seeds first .. first+count-1 (fewer when `seconds` run out); returns the descriptions of those that differ."""
+    t0 = time.time()
+    failed = []
+    for seed in range(first, first + count):
+        if time.time() - t0 > seconds:
+            break
+        what, msg = one_scene(seed)
+        if verbose:
+            print(what + ": " + ("ok" if not msg else "; ".join(msg)), flush=True)
+        if msg:
+            failed.append(what + ": " + "; ".join(msg))
+    return failed
+
+
+if __name__ == "__main__":
+    bad = run(int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3]) if len(sys.argv) > 3 else 1e9, verbose=True)
+    print("done: %d scenes differ" % len(bad), flush=True)
+    sys.exit(1 if bad else 0)
