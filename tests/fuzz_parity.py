@@ -7,9 +7,11 @@ none of which may change a result.  Primary-hit ids and t/alpha/beta in the cull
 over one to three frames and the hits of the ray batches are compared bit for bit.
 
     python tests/fuzz_parity.py <first seed> <count> [seconds]      # needs an MI355X
+    python tests/fuzz_parity.py --cpu <first seed> <count> [seconds]   # the restatement against the reference's own compiled
+                                                                     # sources (oracle/_ref) on the same scenes: no GPU
 
 tests/test_gpu_fuzz.py runs a fixed range of seeds with the GPU suite; campaigns over seeds 100..4099 and 5000..10999 (fifteen
-minutes on one MI355X) found no difference."""
+minutes on one MI355X) found no difference, nor did seeds 100..2099 with --cpu."""
 import os
 import sys
 import time
@@ -35,8 +37,8 @@ def differ(a, b):
     return int(neq.sum())
 
 
-def one_scene(seed):
-    """Builds the scene of `seed`, renders and traces it on both sides; returns (description, list of differences)."""
+def scene_of(seed):
+    """The scene, camera and render parameters of `seed`; also the generator, for what the caller draws further."""
     rng = np.random.default_rng(1000 + seed)
     kind = int(rng.integers(0, 4))
     w, h = int(rng.integers(3, 90)), int(rng.integers(3, 70))
@@ -66,6 +68,34 @@ def one_scene(seed):
     sc.seed = int(rng.integers(0, 2**31))
     if rng.integers(0, 3) == 0:
         sc.bg = tuple(float(x) for x in rng.uniform(0, 1, 3))
+    return sc, rng, kind
+
+
+def awkward_rays(sc, rng, nr=6000):
+    """Rays from inside the scene's bounds with the awkward ones mixed in."""
+    V = sc.tris["v"].reshape(-1, 4)[:, :3].astype(np.float32)
+    o = rng.uniform(V.min(0) - 1, V.max(0) + 1, (nr, 3)).astype(np.float32)
+    d = rng.normal(0, 1, (nr, 3)).astype(np.float32)
+    d[:300, int(rng.integers(0, 3))] = 0
+    a, b = rng.choice(3, 2, replace=False)
+    d[300:500, a] = 0
+    d[300:500, b] = 0
+    o[500:1500] = np.round(o[500:1500])
+    d[1500:1600] *= np.float32(1e-6)
+    d[1600:1700] *= np.float32(1e6)
+    k = rng.integers(0, len(V), 600)
+    k2 = rng.integers(0, len(V), 600)
+    o[1700:2300] = V[k]                      # from vertices
+    d[1700:2300] = V[k2] - V[k]              # towards other vertices: edge and corner hits
+    o[2300:2600, 0] = V[rng.integers(0, len(V), 300), 0]   # on x planes of boxes, running along them
+    d[2300:2600, 0] = 0
+    return o, d
+
+
+def one_scene(seed):
+    """Builds the scene of `seed`, renders and traces it on both sides; returns (description, list of differences)."""
+    sc, rng, kind = scene_of(seed)
+    w, h, depth = sc.width, sc.height, sc.max_depth
     # scheduling knobs of the traversal, read when the scene object is created
     env = {}
     if rng.integers(0, 4) != 0:
@@ -122,24 +152,7 @@ def one_scene(seed):
     if rays != O.ray_count():
         msg.append("rays: %d against %d" % (rays, O.ray_count()))
     st = rt.stats()
-    # rays from inside the scene's bounds with the awkward ones mixed in
-    V = sc.tris["v"].reshape(-1, 4)[:, :3].astype(np.float32)
-    nr = 6000
-    o = rng.uniform(V.min(0) - 1, V.max(0) + 1, (nr, 3)).astype(np.float32)
-    d = rng.normal(0, 1, (nr, 3)).astype(np.float32)
-    d[:300, int(rng.integers(0, 3))] = 0
-    a, b = rng.choice(3, 2, replace=False)
-    d[300:500, a] = 0
-    d[300:500, b] = 0
-    o[500:1500] = np.round(o[500:1500])
-    d[1500:1600] *= np.float32(1e-6)
-    d[1600:1700] *= np.float32(1e6)
-    k = rng.integers(0, len(V), 600)
-    k2 = rng.integers(0, len(V), 600)
-    o[1700:2300] = V[k]                      # from vertices
-    d[1700:2300] = V[k2] - V[k]              # towards other vertices: edge and corner hits
-    o[2300:2600, 0] = V[rng.integers(0, len(V), 300), 0]   # on x planes of boxes, running along them
-    d[2300:2600, 0] = 0
+    o, d = awkward_rays(sc, rng)
     ids_ro, tab_ro = O.closest_hits(o, d)
     for m in (0, 1):
         ids_rg, tab_rg = rt.trace_rays(o, d, m)
@@ -156,14 +169,55 @@ def one_scene(seed):
     return what, msg
 
 
-def run(first, count, seconds=1e9, verbose=False):
+def one_scene_cpu(seed):
+    """The CPU restatement against the reference's own compiled sources (oracle/_ref, where it has been built) on the scene
+    of `seed`: camera, tree, rays, closest hits of the primary rays and of the awkward batch, candidate lists, radiance of the
+    recursive color() with the reference's generators."""
+    from scene_io import nodes_fields
+    sc, rng, kind = scene_of(seed)
+    sc.width, sc.height = min(sc.width, 24), min(sc.height, 16)   # the reference traces every ray on a thread of its own here
+    O, R = load_into(binding.Oracle(), sc), load_into(binding.Reference(), sc)
+    msg = []
+    if differ(O.get_camera(), R.get_camera()):
+        msg.append("camera")
+    if not np.array_equal(nodes_fields(O.get_nodes()), nodes_fields(R.get_nodes())):
+        msg.append("tree")
+    rays_o = np.array([O.get_ray(x, y) for y in range(sc.height) for x in range(sc.width)]).reshape(-1, 2, 4)
+    rays_r = np.array([R.get_ray(x, y) for y in range(sc.height) for x in range(sc.width)]).reshape(-1, 2, 4)
+    if differ(rays_o, rays_r):
+        msg.append("camera rays")
+    ids_o, tab_o = O.primary_hits()
+    ids_r, tab_r = R.closest_hits(rays_r[:, 0, :3], rays_r[:, 1, :3])
+    if not np.array_equal(ids_o, ids_r) or differ(tab_o, tab_r):
+        msg.append("primary hits")
+    o, d = awkward_rays(sc, rng, 3000)
+    ids_o, tab_o = O.closest_hits(o, d)
+    ids_r, tab_r = R.closest_hits(o, d)
+    if not np.array_equal(ids_o, ids_r) or differ(tab_o, tab_r):
+        msg.append("ray batch: %d ids differ" % int((ids_o != ids_r).sum()))
+    for i in range(0, len(o), 211):
+        if not np.array_equal(O.bvh_hit(o[i], d[i]), R.bvh_hit(o[i], d[i])):
+            msg.append("candidate list of ray %d" % i)
+            break
+    col_o, tir = O.color_mt(0, rays_r[:, 0, :3], rays_r[:, 1, :3], fresh_each=True)
+    col_r = R.color(0, rays_r[:, 0, :3], rays_r[:, 1, :3], fresh_each=True)
+    ok = tir == 0
+    n = differ(col_o[ok][:, :3], col_r[ok][:, :3])
+    if n:
+        msg.append("radiance: %d values differ" % n)
+    what = "seed %d kind %d %dx%d depth %d diffuse %d specular %d, %d triangles, %d samples past total internal reflection left out" % (
+        seed, kind, sc.width, sc.height, sc.max_depth, sc.n_diff, sc.n_spec, len(sc.tris), int((~ok).sum()))
+    return what, msg
+
+
+def run(first, count, seconds=1e9, verbose=False, scene=None):
     """Scenes of seeds first .. first+count-1 (fewer when `seconds` run out); returns the descriptions of those that differ."""
     t0 = time.time()
     failed = []
     for seed in range(first, first + count):
         if time.time() - t0 > seconds:
             break
-        what, msg = one_scene(seed)
+        what, msg = (scene or one_scene)(seed)
         if verbose:
             print(what + ": " + ("ok" if not msg else "; ".join(msg)), flush=True)
         if msg:
@@ -172,6 +226,8 @@ def run(first, count, seconds=1e9, verbose=False):
 
 
 if __name__ == "__main__":
-    bad = run(int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3]) if len(sys.argv) > 3 else 1e9, verbose=True)
+    cpu = "--cpu" in sys.argv   # the restatement against the compiled reference instead (no GPU)
+    args = [a for a in sys.argv[1:] if a != "--cpu"]
+    bad = run(int(args[0]), int(args[1]), float(args[2]) if len(args) > 2 else 1e9, verbose=True, scene=one_scene_cpu if cpu else None)
     print("done: %d scenes differ" % len(bad), flush=True)
     sys.exit(1 if bad else 0)

@@ -87,6 +87,15 @@ def test_render_rows_sequential_generators():
     assert np.array_equal(O.tonemap(acc_o, 1).reshape(sc.height, sc.width, 3), out_r)
 
 
+def test_random_scenes_cameras_and_rays_equal_the_reference():
+    """A fixed range of the seeds of tests/fuzz_parity.py: random scenes of four kinds, cameras, parameters and batches of
+    awkward rays; camera, tree, rays, hits, candidate lists and recursive radiance of the restatement against the compiled
+    reference, bit for bit."""
+    import fuzz_parity
+    failed = fuzz_parity.run(0, 16, scene=fuzz_parity.one_scene_cpu)
+    assert not failed, "\n".join(failed)
+
+
 def test_texture_files_decode_like_the_reference(tmp_path):
     """Texture::Texture(path) (src/Texture.cpp:4-8, the reference's vendored stb_image, three channels, flipped)
     against the loaders of rtx_image.cpp / rtx_jpeg.cpp: JPEG baseline and progressive in every subsampling, with
