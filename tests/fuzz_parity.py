@@ -9,9 +9,11 @@ over one to three frames and the hits of the ray batches are compared bit for bi
     python tests/fuzz_parity.py <first seed> <count> [seconds]      # needs an MI355X
     python tests/fuzz_parity.py --cpu <first seed> <count> [seconds]   # the restatement against the reference's own compiled
                                                                      # sources (oracle/_ref) on the same scenes: no GPU
+    python tests/fuzz_parity.py --big <first seed> <count> [seconds]   # frames of up to 1024x640 over up to 400 k triangles:
+                                                                     # production against binary-tree traversal, CPU on blocks
 
 tests/test_gpu_fuzz.py runs a fixed range of seeds with the GPU suite; campaigns over seeds 100..4099 and 5000..10999 (fifteen
-minutes on one MI355X) found no difference, nor did seeds 100..2099 with --cpu."""
+minutes on one MI355X) found no difference, nor did seeds 100..2099 with --cpu or seeds 0..399 with --big."""
 import os
 import sys
 import time
@@ -210,6 +212,69 @@ def one_scene_cpu(seed):
     return what, msg
 
 
+def one_scene_big(seed):
+    """Larger frames (the one-ray-per-lane kernel with many chunks per wave, the queues of every level in the millions): an
+    atrium or a displaced mesh of up to a few hundred thousand triangles at up to 1024x640.  The production traversal against
+    the binary-tree kernel over the reference's own tree (RTX_TRACE_BINARY=1: every box with the exact predicate), whole
+    accumulators and ray counts, and against the CPU restatement on pixel blocks scattered over the frame."""
+    from util import scattered_blocks
+    rng = np.random.default_rng(77000 + seed)
+    w, h = int(rng.integers(300, 1025)), int(rng.integers(200, 641))
+    depth = int(rng.integers(2, 5))
+    if rng.integers(0, 2):
+        sc = scenes.atrium_scene(width=w, height=h, max_depth=depth, detail=float(rng.uniform(0.2, 1.0)), tex_size=64, seed=seed)
+    else:
+        sc = scenes.heightfield_scene(n_tris=int(rng.integers(20000, 400000)), width=w, height=h, seed=seed)
+        sc.max_depth, sc.n_diff, sc.n_spec = depth, 1, 1
+    eye = np.array(sc.eye, np.float32) + rng.normal(0, 2, 3).astype(np.float32)
+    at = np.array(sc.at, np.float32) + rng.normal(0, 2, 3).astype(np.float32)
+    sc.eye, sc.at = tuple(float(x) for x in eye), tuple(float(x) for x in at)
+    sc.focal = float(rng.uniform(20, 90))
+    sc.seed = int(rng.integers(0, 2**31))
+    nodes = api.build_bvh(sc.tris)
+    frames = int(rng.integers(1, 3))
+    env = {"RTX_RETIRE_BACKLOG": str(rng.choice([0, 128, 400])), "RTX_WIDE_STACK": str(rng.choice([16, 24])),
+           "RTX_TRACE_CHUNK": str(rng.choice([64, 256]))}
+    got = {}
+    for binary in (False, True):
+        saved = {k: os.environ.get(k) for k in KNOBS + ("RTX_TRACE_BINARY",)}
+        os.environ.update(env)
+        if binary:
+            os.environ["RTX_TRACE_BINARY"] = "1"
+        try:
+            rt = api.RayTracer(0)
+        finally:
+            for k, v in saved.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+        rt.load_scene(sc, nodes)
+        rt.reset()
+        rt.render(1, frames)
+        st = rt.stats()
+        got[binary] = (rt.accum(), st["rays"], st["rays_per_level"])
+        del rt
+    msg = []
+    n = differ(got[False][0], got[True][0])
+    if n:
+        msg.append("accumulator, production against binary-tree traversal: %d values differ" % n)
+    if got[False][1:] != got[True][1:]:
+        msg.append("ray counts: %s against %s" % (got[False][2], got[True][2]))
+    O = binding.Oracle()
+    load_into(O, sc, build=False)
+    O.set_nodes(nodes)
+    xy = scattered_blocks(sc.width, sc.height, 24, seed=seed)
+    acc = np.zeros(got[False][0].shape, np.float32)
+    for f in range(1, frames + 1):
+        O.render_pixels(f, xy, acc, nthreads=16)
+    n = differ(acc[xy[:, 1], xy[:, 0], :3], got[False][0][xy[:, 1], xy[:, 0], :3])
+    if n:
+        msg.append("accumulator against the CPU on %d pixels: %d values differ" % (len(xy), n))
+    what = "seed %d %s %dx%d depth %d, %d triangles, %d frame(s), %d rays, %s" % (
+        seed, sc.name, w, h, depth, len(sc.tris), frames, got[False][1], " ".join("%s=%s" % (k[4:], v) for k, v in env.items()))
+    return what, msg
+
+
 def run(first, count, seconds=1e9, verbose=False, scene=None):
     """Scenes of seeds first .. first+count-1 (fewer when `seconds` run out); returns the descriptions of those that differ."""
     t0 = time.time()
@@ -227,7 +292,9 @@ def run(first, count, seconds=1e9, verbose=False, scene=None):
 
 if __name__ == "__main__":
     cpu = "--cpu" in sys.argv   # the restatement against the compiled reference instead (no GPU)
-    args = [a for a in sys.argv[1:] if a != "--cpu"]
-    bad = run(int(args[0]), int(args[1]), float(args[2]) if len(args) > 2 else 1e9, verbose=True, scene=one_scene_cpu if cpu else None)
+    big = "--big" in sys.argv   # larger frames: production against binary-tree traversal, and the CPU on scattered blocks
+    args = [a for a in sys.argv[1:] if a not in ("--cpu", "--big")]
+    bad = run(int(args[0]), int(args[1]), float(args[2]) if len(args) > 2 else 1e9, verbose=True,
+              scene=one_scene_cpu if cpu else one_scene_big if big else None)
     print("done: %d scenes differ" % len(bad), flush=True)
     sys.exit(1 if bad else 0)

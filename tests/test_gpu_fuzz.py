@@ -10,3 +10,9 @@ def test_random_scenes_cameras_and_schedules_equal_the_restatement():
     import fuzz_parity
     failed = fuzz_parity.run(0, 60)
     assert not failed, "\n".join(failed)
+
+
+def test_random_large_frames_equal_the_binary_tree_traversal_and_the_restatement():
+    import fuzz_parity
+    failed = fuzz_parity.run(0, 8, scene=fuzz_parity.one_scene_big)
+    assert not failed, "\n".join(failed)
