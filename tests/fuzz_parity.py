@@ -11,9 +11,11 @@ over one to three frames and the hits of the ray batches are compared bit for bi
                                                                      # sources (oracle/_ref) on the same scenes: no GPU
     python tests/fuzz_parity.py --big <first seed> <count> [seconds]   # frames of up to 1024x640 over up to 400 k triangles:
                                                                      # production against binary-tree traversal, CPU on blocks
+    python tests/fuzz_parity.py --batching <first seed> <count> [seconds]   # one image however the call is cut up: frames per
+                                                                     # call, arena limits, batch sizes, tile shares, tile runs
 
 tests/test_gpu_fuzz.py runs a fixed range of seeds with the GPU suite; campaigns over seeds 100..4099 and 5000..10999 (fifteen
-minutes on one MI355X) found no difference, nor did seeds 100..2099 with --cpu or seeds 0..399 with --big."""
+minutes on one MI355X) found no difference, nor did seeds 100..2099 with --cpu, seeds 0..399 with --big or seeds 0..599 with --batching."""
 import os
 import sys
 import time
@@ -275,6 +277,123 @@ def one_scene_big(seed):
     return what, msg
 
 
+def one_scene_batching(seed):
+    """How a call is cut up must not show in the image: frames one call each with the default work arena are the baseline
+    (its first frame checked against the CPU restatement on scattered blocks); then all frames in one call (merged pixel
+    batches), a work arena between tight and ample (many batches, queue capacities that have to grow), queues sized for the
+    worst case, batches limited to a random number of pixel blocks, the image composed from n interleaved tile shares or
+    from runs of consecutive tiles rendered one after the other, the 8-bit images of the frames of a merged call."""
+    from util import scattered_blocks
+    rng = np.random.default_rng(31000 + seed)
+    w, h = int(rng.integers(70, 420)), int(rng.integers(60, 300))
+    depth = int(rng.integers(1, 5))
+    nd, ns = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+    if rng.integers(0, 2):
+        sc = scenes.atrium_scene(width=w, height=h, max_depth=depth, n_diff=nd, n_spec=ns, detail=float(rng.uniform(0.1, 0.4)), tex_size=32, seed=seed)
+    else:
+        sc = scenes.mixed_scene(seed=seed, width=w, height=h, max_depth=depth, n_diff=nd, n_spec=ns, with_sky=bool(rng.integers(0, 2)),
+                                detail=float(rng.uniform(0.5, 1.5)))
+    sc.seed = int(rng.integers(0, 2**31))
+    nodes = api.build_bvh(sc.tris)
+    frames = int(rng.integers(1, 5))
+    first = int(rng.integers(1, 50))
+    msg = []
+
+    def tracer(env=None):
+        saved = {k: os.environ.get(k) for k in ("RTX_MERGE_BLOCKS", "RTX_WORST_CASE_QUEUES")}
+        os.environ.update(env or {})
+        try:
+            rt = api.RayTracer(0)
+        finally:
+            for k, v in saved.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+        rt.load_scene(sc, nodes)
+        rt.reset()
+        return rt
+
+    rt = tracer()
+    images = []
+    for f in range(first, first + frames):
+        rt.render(f, 1)
+        images.append(api.tonemap(rt.accum(), f - first + 1) if first == 1 else None)
+    base = rt.accum()
+    rays = None
+    O = binding.Oracle()
+    load_into(O, sc, build=False)
+    O.set_nodes(nodes)
+    xy = scattered_blocks(sc.width, sc.height, 12, seed=seed)
+    acc = np.zeros(base.shape, np.float32)
+    for f in range(first, first + frames):
+        O.render_pixels(f, xy, acc, nthreads=16)
+    n = differ(acc[xy[:, 1], xy[:, 0], :3], base[xy[:, 1], xy[:, 0], :3])
+    if n:
+        msg.append("baseline against the CPU on %d pixels: %d values differ" % (len(xy), n))
+
+    def check(what, a):
+        n = differ(base, a)
+        if n:
+            msg.append("%s: %d values differ" % (what, n))
+
+    rt.reset()
+    rt.render(first, frames)
+    check("one call over %d frames" % frames, rt.accum())
+    # a tight work arena: a few thousand bytes per sample of one 4x4-pixel block upwards
+    per_block = 16 * 4 * 3000
+    arena = int(per_block * rng.uniform(1.0, 40.0))
+    rt.set_arena_bytes(arena)
+    rt.reset()
+    try:
+        rt.render(first, frames)
+        st = rt.stats()
+        check("work arena of %d bytes (%d batches, %d retries)" % (arena, st["chunks"], st["queue_retries"]), rt.accum())
+    except api.RtxError as e:
+        if "arena" not in str(e):
+            msg.append("work arena of %d bytes: %s" % (arena, e))
+    rt.set_arena_bytes(0)
+    del rt
+    rt = tracer({"RTX_WORST_CASE_QUEUES": "1", "RTX_MERGE_BLOCKS": str(int(rng.integers(1, 3000)))})
+    rt.render(first, frames)
+    check("worst-case queues, limited batches", rt.accum())
+    if first == 1:
+        rt.reset()
+        got = rt.render_images(1, frames)
+        for k in range(frames):
+            if not np.array_equal(got[k].reshape(-1, 3), images[k]):
+                msg.append("8-bit image of frame %d of a merged call" % (k + 1))
+    # tile shares
+    n_sh = int(rng.choice([2, 3, 5]))
+    merged = np.zeros_like(base)
+    tiles_x, tiles_y = (sc.width + 63) // 64, (sc.height + 63) // 64
+    for r in range(n_sh):
+        rt.set_tiles(r, n_sh, -1)
+        rt.reset()
+        rt.render(first, frames)
+        part = rt.accum()
+        for t in range(r, tiles_x * tiles_y, n_sh):
+            y0, x0 = (t // tiles_x) * 64, (t % tiles_x) * 64
+            merged[y0:y0 + 64, x0:x0 + 64] = part[y0:y0 + 64, x0:x0 + 64]
+            part[y0:y0 + 64, x0:x0 + 64] = 0
+        if part.any():
+            msg.append("share %d of %d wrote outside its tiles" % (r, n_sh))
+    check("%d interleaved tile shares" % n_sh, merged)
+    # runs of consecutive tiles into one accumulator, frame by frame (what dynamic balancing does)
+    rt.reset()
+    for f in range(first, first + frames):
+        t = 0
+        while t < tiles_x * tiles_y:
+            cnt = int(rng.integers(1, 6))
+            rt.set_tiles(t, 1, cnt)
+            rt.render(f, 1)
+            t += cnt
+    rt.set_tiles(0, 1, -1)
+    check("runs of consecutive tiles", rt.accum())
+    what = "seed %d %s %dx%d depth %d diffuse %d specular %d, %d triangles, frames %d..%d" % (
+        seed, sc.name, w, h, depth, nd, ns, len(sc.tris), first, first + frames - 1)
+    return what, msg
+
+
 def run(first, count, seconds=1e9, verbose=False, scene=None):
     """Scenes of seeds first .. first+count-1 (fewer when `seconds` run out); returns the descriptions of those that differ."""
     t0 = time.time()
@@ -293,8 +412,9 @@ def run(first, count, seconds=1e9, verbose=False, scene=None):
 if __name__ == "__main__":
     cpu = "--cpu" in sys.argv   # the restatement against the compiled reference instead (no GPU)
     big = "--big" in sys.argv   # larger frames: production against binary-tree traversal, and the CPU on scattered blocks
-    args = [a for a in sys.argv[1:] if a not in ("--cpu", "--big")]
+    batching = "--batching" in sys.argv   # how a call is cut into batches, shares and frames must not show in the image
+    args = [a for a in sys.argv[1:] if a not in ("--cpu", "--big", "--batching")]
     bad = run(int(args[0]), int(args[1]), float(args[2]) if len(args) > 2 else 1e9, verbose=True,
-              scene=one_scene_cpu if cpu else one_scene_big if big else None)
+              scene=one_scene_cpu if cpu else one_scene_big if big else one_scene_batching if batching else None)
     print("done: %d scenes differ" % len(bad), flush=True)
     sys.exit(1 if bad else 0)

@@ -16,3 +16,9 @@ def test_random_large_frames_equal_the_binary_tree_traversal_and_the_restatement
     import fuzz_parity
     failed = fuzz_parity.run(0, 8, scene=fuzz_parity.one_scene_big)
     assert not failed, "\n".join(failed)
+
+
+def test_random_ways_of_cutting_a_call_up_give_one_image():
+    import fuzz_parity
+    failed = fuzz_parity.run(0, 10, scene=fuzz_parity.one_scene_batching)
+    assert not failed, "\n".join(failed)
