@@ -730,17 +730,13 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(S
 			}
 #endif
 			// A launch lasts as long as its longest ray, and one lane walks one node after the other.  A ray
-			// that has used up its allowance of walk steps starts over in k_trace_long, where a whole wave works on it; so
-			// does a ray that comes to a node with no room left for the node's children (in the binary-tree kernel, whose
-			// stack covers its whole tree, where the wave-per-ray kernel is not run).  (Rare: the wave asks once whether any
-			// of its lanes is there, so that the step of the others does not run through the hand-over's branches.)
-			--visitsLeft;
-			const bool leaves = cur >= 0 && (visitsLeft < 0 || top < stkFloor);
-			if (__builtin_amdgcn_ballot_w64(leaves) != 0ull) {
-				if (leaves) {
-					if (visitsLeft < 0 || smallQueue >= 0) longList[atomicAdd(longCount, 1u)] = j;
-					else unsafeList[atomicAdd(unsafeCount, 1u)] = j;
-					if (STATS && visitsLeft >= 0) overflows++;
+			// that has used up its allowance starts over in k_trace_long, where a whole wave works on it.  (Rare: the
+			// wave asks once whether any of its lanes is there, so that the step of the others does not run through the
+			// hand-over's branches.)
+			if (cur >= 0) --visitsLeft;
+			if (__builtin_amdgcn_ballot_w64(visitsLeft < 0) != 0ull) {
+				if (cur >= 0 && visitsLeft < 0) {
+					longList[atomicAdd(longCount, 1u)] = j;
 					busy = false;
 					cur = -1;
 					top = stkEmpty;
@@ -797,6 +793,19 @@ __global__ __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(S
 				RTX_CSWAP(1, 3)
 				RTX_CSWAP(1, 2)
 #undef RTX_CSWAP
+				if (__builtin_amdgcn_ballot_w64(top < stkFloor) != 0ull) {
+					if (top < stkFloor) {
+						// no room: the ray starts over in the wave-per-ray kernel, whose stack is a thousand entries deep (in
+						// the binary-tree kernel, whose stack covers its whole tree, where that kernel is not run)
+						if (smallQueue >= 0) longList[atomicAdd(longCount, 1u)] = j;
+						else unsafeList[atomicAdd(unsafeCount, 1u)] = j;
+						if (STATS) overflows++;
+						busy = false;
+						top = stkEmpty;
+						nh = 0;
+						pend0 = -1;
+					}
+				}
 				// all four go below the top, the farthest next to it; the top then moves down over the nh entered ones
 				lds_int* low = top - 4 * ROW;
 				asm("" : "+v"(low));  // (one subtraction and four constant offsets; seen through, it becomes four additions)
