@@ -14,8 +14,8 @@ over one to three frames and the hits of the ray batches are compared bit for bi
     python tests/fuzz_parity.py --batching <first seed> <count> [seconds]   # one image however the call is cut up: frames per
                                                                      # call, arena limits, batch sizes, tile shares, tile runs
 
-tests/test_gpu_fuzz.py runs a fixed range of seeds with the GPU suite; campaigns over seeds 100..4099, 5000..10999, 20000..32503 and 40000..46621 (forty
-minutes on one MI355X) found no difference, nor did seeds 100..2099 with --cpu, 0..399 and 1000..1473 with --big or 0..599 and
+tests/test_gpu_fuzz.py runs a fixed range of seeds with the GPU suite; campaigns over seeds 100..4099, 5000..10999, 20000..32503, 40000..46621 and
+60000..72567 (an hour on one MI355X) found no difference, nor did seeds 100..2099 and 3000..7670 with --cpu, 0..399 and 1000..1473 with --big or 0..599 and
 1000..1799 with --batching."""
 import os
 import sys
